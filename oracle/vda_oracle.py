@@ -1,0 +1,371 @@
+"""CPU oracle for the Video Depth Anything per-window forward pass and the window/stitch host logic.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the shipped package imports this file; only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may use it, and only as the checker
+or the timed CPU baseline.
+
+It is a functional, fp32, plain-torch/numpy restatement of the reference algorithm that works directly on a
+``state_dict`` (no nn.Module tree).  Each function cites the reference lines it follows.  It is pinned to the
+reference by the golden vectors under ``tests/golden/`` which ``oracle/make_goldens.py`` produced by importing
+the unmodified reference model in the build container (the reference's own tests hold no fixtures for this
+path).  The OpenCV bicubic image resize of the preprocessing step is NOT covered (cv2 is absent everywhere this
+runs): frames are fed at network size, and that one step is "parity unpinned".
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ENCODERS = {"vits": (384, 12, 6, (2, 5, 8, 11)), "vitl": (1024, 24, 16, (4, 11, 17, 23))}
+
+INFER_LEN = 32
+OVERLAP = 10
+KEYFRAMES = [0, 12, 24, 25, 26, 27, 28, 29, 30, 31]
+INTERP_LEN = 8
+
+
+def _t(sd, key, like):
+    v = sd[key]
+    if not torch.is_tensor(v):
+        v = torch.from_numpy(np.asarray(v))
+    return v.to(device=like.device, dtype=torch.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# encoder
+# ----------------------------------------------------------------------------------------------------------
+def pos_embed_for(pos_embed, hp, wp):
+    """Positional table for an ``hp x wp`` patch grid (reference: dinov2.py:179-210).
+
+    The stored table is returned untouched for the square 37x37 grid; otherwise the 37x37 patch part is
+    resampled bicubically with an explicit scale factor of ``(n + 0.1) / 37`` per axis (align_corners=False,
+    no antialias) and the class entry is passed through.
+    """
+    n_stored = pos_embed.shape[1] - 1
+    g = int(math.sqrt(n_stored))
+    if hp * wp == n_stored and hp == wp:
+        return pos_embed
+    pe = pos_embed.float()
+    cls_pe, patch_pe = pe[:, :1], pe[:, 1:]
+    dim = pe.shape[-1]
+    sy, sx = float(hp + 0.1) / g, float(wp + 0.1) / g
+    grid = patch_pe.reshape(1, g, g, dim).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, scale_factor=(sy, sx), mode="bicubic", antialias=False)
+    assert grid.shape[-2] == hp and grid.shape[-1] == wp
+    return torch.cat([cls_pe, grid.permute(0, 2, 3, 1).reshape(1, hp * wp, dim)], dim=1)
+
+
+def encoder_tokens(sd, x):
+    """Patch embedding, class token and positional table (reference: dinov2.py:212-231, patch_embed.py:69-82)."""
+    p = "pretrained."
+    tok = F.conv2d(x, _t(sd, p + "patch_embed.proj.weight", x), _t(sd, p + "patch_embed.proj.bias", x), stride=14)
+    n, d, hp, wp = tok.shape
+    tok = tok.flatten(2).transpose(1, 2)
+    cls = _t(sd, p + "cls_token", x).expand(n, -1, -1)
+    tok = torch.cat([cls, tok], dim=1)
+    return tok + pos_embed_for(_t(sd, p + "pos_embed", x), hp, wp)
+
+
+def encoder_block(sd, i, x, heads):
+    """One pre-norm transformer block with LayerScale (reference: block.py:82-107, attention.py:49-62,
+    mlp.py:35-41, layer_scale.py:27-28)."""
+    b = f"pretrained.blocks.{i}."
+    n, s, d = x.shape
+    hd = d // heads
+    y = F.layer_norm(x, (d,), _t(sd, b + "norm1.weight", x), _t(sd, b + "norm1.bias", x), 1e-6)
+    qkv = F.linear(y, _t(sd, b + "attn.qkv.weight", x), _t(sd, b + "attn.qkv.bias", x))
+    qkv = qkv.reshape(n, s, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
+    a = torch.softmax(q @ k.transpose(-2, -1), dim=-1) @ v
+    a = a.transpose(1, 2).reshape(n, s, d)
+    a = F.linear(a, _t(sd, b + "attn.proj.weight", x), _t(sd, b + "attn.proj.bias", x))
+    x = x + a * _t(sd, b + "ls1.gamma", x)
+    y = F.layer_norm(x, (d,), _t(sd, b + "norm2.weight", x), _t(sd, b + "norm2.bias", x), 1e-6)
+    y = F.gelu(F.linear(y, _t(sd, b + "mlp.fc1.weight", x), _t(sd, b + "mlp.fc1.bias", x)))
+    y = F.linear(y, _t(sd, b + "mlp.fc2.weight", x), _t(sd, b + "mlp.fc2.bias", x))
+    return x + y * _t(sd, b + "ls2.gamma", x)
+
+
+def encoder_taps(sd, x, encoder, frame_chunk=8):
+    """Four normalised intermediate patch-token maps (reference: dinov2.py:271-281, 297-321).
+
+    Frames are independent in the encoder, so they are processed ``frame_chunk`` at a time to bound the
+    size of the materialised attention matrix; the arithmetic per frame is unchanged.
+    """
+    d, depth, heads, taps = ENCODERS[encoder]
+    outs = [[] for _ in taps]
+    nw, nb = _t(sd, "pretrained.norm.weight", x), _t(sd, "pretrained.norm.bias", x)
+    for s0 in range(0, x.shape[0], frame_chunk):
+        t = encoder_tokens(sd, x[s0:s0 + frame_chunk])
+        for i in range(depth):
+            t = encoder_block(sd, i, t, heads)
+            if i in taps:
+                y = F.layer_norm(t, (d,), nw, nb, 1e-6)
+                outs[taps.index(i)].append(y[:, 1:])          # class token is dropped (use_clstoken=False)
+    return [torch.cat(o, dim=0) for o in outs]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# temporal (motion) module
+# ----------------------------------------------------------------------------------------------------------
+def temporal_attention(sd, pre, h, T, heads=8):
+    """Self-attention over the T frames of every spatial position (reference: motion_module.py:230-297,
+    attention.py:93-111, 182-211).  ``h``: already layer-normed ``[B*T, hw, C]``."""
+    bt, hw, c = h.shape
+    b = bt // T
+    hd = c // heads
+    z = h.reshape(b, T, hw, c).permute(0, 2, 1, 3).reshape(b * hw, T, c)
+    z = z + _t(sd, pre + "pos_encoder.pe", h)[:, :T]
+    q = F.linear(z, _t(sd, pre + "to_q.weight", h))
+    k = F.linear(z, _t(sd, pre + "to_k.weight", h))
+    v = F.linear(z, _t(sd, pre + "to_v.weight", h))
+
+    def split(u):
+        return u.reshape(b * hw, T, heads, hd).permute(0, 2, 1, 3)
+
+    q, k, v = split(q), split(k), split(v)
+    p = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(b * hw, T, c)
+    o = F.linear(o, _t(sd, pre + "to_out.0.weight", h), _t(sd, pre + "to_out.0.bias", h))
+    return o.reshape(b, hw, T, c).permute(0, 2, 1, 3).reshape(bt, hw, c)
+
+
+def temporal_module(sd, idx, x, T):
+    """GroupNorm -> proj_in -> 2x(LN, temporal attention, +res) -> LN, GEGLU feed-forward, +res -> proj_out ->
+    + input (reference: motion_module.py:102-126, 164-177; attention.py:335-338, 382-384).  ``x``: [B*T, C, h, w]."""
+    pre = f"head.motion_modules.{idx}.temporal_transformer."
+    bt, c, hh, ww = x.shape
+    y = F.group_norm(x, 32, _t(sd, pre + "norm.weight", x), _t(sd, pre + "norm.bias", x), 1e-6)
+    y = y.permute(0, 2, 3, 1).reshape(bt, hh * ww, c)
+    y = F.linear(y, _t(sd, pre + "proj_in.weight", x), _t(sd, pre + "proj_in.bias", x))
+    tb = pre + "transformer_blocks.0."
+    for a in (0, 1):
+        n = F.layer_norm(y, (c,), _t(sd, f"{tb}norms.{a}.weight", x), _t(sd, f"{tb}norms.{a}.bias", x), 1e-5)
+        y = temporal_attention(sd, f"{tb}attention_blocks.{a}.", n, T) + y
+    n = F.layer_norm(y, (c,), _t(sd, tb + "ff_norm.weight", x), _t(sd, tb + "ff_norm.bias", x), 1e-5)
+    g = F.linear(n, _t(sd, tb + "ff.net.0.proj.weight", x), _t(sd, tb + "ff.net.0.proj.bias", x))
+    val, gate = g.chunk(2, dim=-1)
+    f = F.linear(val * F.gelu(gate), _t(sd, tb + "ff.net.2.weight", x), _t(sd, tb + "ff.net.2.bias", x))
+    y = f + y
+    y = F.linear(y, _t(sd, pre + "proj_out.weight", x), _t(sd, pre + "proj_out.bias", x))
+    return y.reshape(bt, hh, ww, c).permute(0, 3, 1, 2) + x
+
+
+# ----------------------------------------------------------------------------------------------------------
+# DPT head
+# ----------------------------------------------------------------------------------------------------------
+def residual_conv_unit(sd, pre, x):
+    """conv2(relu(conv1(relu(x)))) + x (reference: util/blocks.py:68-91)."""
+    y = F.conv2d(F.relu(x), _t(sd, pre + "conv1.weight", x), _t(sd, pre + "conv1.bias", x), padding=1)
+    y = F.conv2d(F.relu(y), _t(sd, pre + "conv2.weight", x), _t(sd, pre + "conv2.bias", x), padding=1)
+    return y + x
+
+
+def fusion_block(sd, idx, x0, x1=None, size=None):
+    """RefineNet fusion (reference: util/blocks.py:135-162)."""
+    pre = f"head.scratch.refinenet{idx}."
+    y = x0
+    if x1 is not None:
+        y = y + residual_conv_unit(sd, pre + "resConfUnit1.", x1)
+    y = residual_conv_unit(sd, pre + "resConfUnit2.", y)
+    if size is None:
+        y = F.interpolate(y, scale_factor=2, mode="bilinear", align_corners=True)
+    else:
+        y = F.interpolate(y, size=tuple(size), mode="bilinear", align_corners=True)
+    return F.conv2d(y, _t(sd, pre + "out_conv.weight", x0), _t(sd, pre + "out_conv.bias", x0))
+
+
+def head_forward(sd, taps, hp, wp, T):
+    """Temporal DPT head (reference: dpt_temporal.py:53-114, dpt.py:60-124).  ``taps``: 4 x [B*T, hp*wp, D].
+    Returns ``[B*T, 1, 14hp, 14wp]``.  The reference's 4-frame micro-batching of the last stages is a memory
+    device only (every op there is per-sample), so it is not restated."""
+    h = "head."
+    x0 = taps[0]
+    layers = []
+    for i, tok in enumerate(taps):
+        m = tok.permute(0, 2, 1).reshape(tok.shape[0], tok.shape[-1], hp, wp)
+        m = F.conv2d(m, _t(sd, f"{h}projects.{i}.weight", x0), _t(sd, f"{h}projects.{i}.bias", x0))
+        if i == 0:
+            m = F.conv_transpose2d(m, _t(sd, h + "resize_layers.0.weight", x0), _t(sd, h + "resize_layers.0.bias", x0), stride=4)
+        elif i == 1:
+            m = F.conv_transpose2d(m, _t(sd, h + "resize_layers.1.weight", x0), _t(sd, h + "resize_layers.1.bias", x0), stride=2)
+        elif i == 3:
+            m = F.conv2d(m, _t(sd, h + "resize_layers.3.weight", x0), _t(sd, h + "resize_layers.3.bias", x0), stride=2, padding=1)
+        layers.append(m)
+    l1, l2, l3, l4 = layers
+    l3 = temporal_module(sd, 0, l3, T)
+    l4 = temporal_module(sd, 1, l4, T)
+    sc = h + "scratch."
+    r1 = F.conv2d(l1, _t(sd, sc + "layer1_rn.weight", x0), padding=1)
+    r2 = F.conv2d(l2, _t(sd, sc + "layer2_rn.weight", x0), padding=1)
+    r3 = F.conv2d(l3, _t(sd, sc + "layer3_rn.weight", x0), padding=1)
+    r4 = F.conv2d(l4, _t(sd, sc + "layer4_rn.weight", x0), padding=1)
+    p4 = fusion_block(sd, 4, r4, None, size=r3.shape[2:])
+    p4 = temporal_module(sd, 2, p4, T)
+    p3 = fusion_block(sd, 3, p4, r3, size=r2.shape[2:])
+    p3 = temporal_module(sd, 3, p3, T)
+    p2 = fusion_block(sd, 2, p3, r2, size=r1.shape[2:])
+    p1 = fusion_block(sd, 1, p2, r1, size=None)
+    o = F.conv2d(p1, _t(sd, sc + "output_conv1.weight", x0), _t(sd, sc + "output_conv1.bias", x0), padding=1)
+    o = F.interpolate(o, (14 * hp, 14 * wp), mode="bilinear", align_corners=True)
+    o = F.relu(F.conv2d(o, _t(sd, sc + "output_conv2.0.weight", x0), _t(sd, sc + "output_conv2.0.bias", x0), padding=1))
+    o = F.relu(F.conv2d(o, _t(sd, sc + "output_conv2.2.weight", x0), _t(sd, sc + "output_conv2.2.bias", x0)))
+    return o
+
+
+@torch.no_grad()
+def forward(sd, x, encoder):
+    """``x[B,T,3,H,W]`` -> depth ``[B,T,H,W]`` (reference: video_depth.py:58-65)."""
+    B, T, _, H, W = x.shape
+    hp, wp = H // 14, W // 14
+    x = x.float()
+    taps = encoder_taps(sd, x.flatten(0, 1), encoder)
+    d = head_forward(sd, taps, hp, wp, T)
+    d = F.relu(F.interpolate(d, size=(H, W), mode="bilinear", align_corners=True))
+    return d.squeeze(1).unflatten(0, (B, T))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# host logic: preprocessing size rule, window assembly, stitch
+# ----------------------------------------------------------------------------------------------------------
+def network_size(frame_h, frame_w, input_size=518):
+    """Network input (H, W) for a frame size (reference: video_depth.py:68-72, util/transform.py:51-107 with
+    keep_aspect_ratio, lower_bound, multiple of 14).  The reference's 'cuda' 420-pixel clamp
+    (video_depth.py:75-78) is not part of this CPU oracle."""
+    ratio = max(frame_h, frame_w) / min(frame_h, frame_w)
+    if ratio > 1.78:
+        input_size = int(input_size * 1.777 / ratio)
+        input_size = round(input_size / 14) * 14
+    scale = max(input_size / frame_w, input_size / frame_h)
+
+    def snap(v):
+        y = int(np.round(v / 14) * 14)
+        if y < input_size:
+            y = int(np.ceil(v / 14) * 14)
+        return y
+
+    return snap(scale * frame_h), snap(scale * frame_w)
+
+
+def normalize_frame(frame_u8):
+    """uint8 HWC frame at network size -> float32 CHW (reference: video_depth.py:120, util/transform.py:134,147-148).
+    The arithmetic is float32/255 then float64 mean/std, cast to float32 last, as numpy does with python lists."""
+    img = frame_u8.astype(np.float32) / 255.0
+    img = (img - [0.485, 0.456, 0.406]) / [0.229, 0.224, 0.225]
+    return np.ascontiguousarray(np.transpose(img, (2, 0, 1))).astype(np.float32)
+
+
+def scale_shift(pred, target):
+    """Closed-form least squares ``target ~ s*pred + t`` with an all-ones mask, in float32
+    (reference: utils/util.py:40-62)."""
+    pred = pred.astype(np.float32)
+    target = target.astype(np.float32)
+    a00 = np.sum(pred * pred)
+    a01 = np.sum(pred)
+    a11 = np.float32(pred.size)
+    b0 = np.sum(pred * target)
+    b1 = np.sum(target)
+    det = a00 * a11 - a01 * a01
+    if det != 0:
+        return (a11 * b0 - a01 * b1) / det, (-a01 * b0 + a00 * b1) / det
+    return 1, 0
+
+
+def blend(pre, post):
+    """Linear cross-fade, weight of ``post`` rising 0 -> 1 (reference: utils/util.py:65-74)."""
+    n = len(pre)
+    step = 1.0 / (n - 1)
+    w = [0.0] + [i * step for i in range(1, n - 1)] + [1.0]
+    return [pre[i] * (1 - w[i]) + post[i] * w[i] for i in range(n)]
+
+
+def window_plan(n_frames, batch_size=32):
+    """Per window: the list of (source kind, index) that fill its slots (reference: video_depth.py:97-103,
+    112-132).  ``("new", j)`` is padded video frame j; ``("prev", k)`` is slot k of the previous window's input."""
+    L = min(INFER_LEN, batch_size)
+    O = min(OVERLAP, L // 2)
+    step = L - O
+    pad = (step - n_frames % step) % step + (L - step)
+    plan = []
+    for w, f0 in enumerate(range(0, n_frames, step)):
+        slots = [("new", min(f0 + i, n_frames - 1)) for i in range(L)]
+        if w > 0 and O > 0:
+            kf = [k for k in KEYFRAMES if k < L][:O]
+            for i, k in enumerate(kf):
+                slots[i] = ("prev", k)
+        plan.append(slots)
+    return plan, L, O, n_frames + pad
+
+
+def stitch(depth_list, n_frames, batch_size=32):
+    """Affine alignment of consecutive windows on two key frames and an 8-frame cross-fade
+    (reference: video_depth.py:166-209).  ``depth_list``: per-slot float32 maps of all windows, concatenated."""
+    L = min(INFER_LEN, batch_size)
+    if L < INFER_LEN or batch_size < INFER_LEN:
+        return np.stack(depth_list[:n_frames], axis=0)
+    out, ref = [], []
+    align_len = OVERLAP - INTERP_LEN
+    kf = KEYFRAMES[:align_len]
+    for f0 in range(0, len(depth_list), INFER_LEN):
+        if not out:
+            out += depth_list[:INFER_LEN]
+            ref = [depth_list[f0 + k] for k in kf]
+            continue
+        cur = [depth_list[f0 + i] for i in range(len(kf))]
+        s, t = scale_shift(np.concatenate(cur), np.concatenate(ref))
+        post = []
+        for d in depth_list[f0 + align_len:f0 + OVERLAP]:
+            d = d * s + t
+            d[d < 0] = 0
+            post.append(d)
+        out[-INTERP_LEN:] = blend(out[-INTERP_LEN:], post)
+        for i in range(OVERLAP, INFER_LEN):
+            d = depth_list[f0 + i] * s + t
+            d[d < 0] = 0
+            out.append(d)
+        ref = ref[:1]
+        for k in kf[1:]:
+            d = depth_list[f0 + k] * s + t
+            d[d < 0] = 0
+            ref.append(d)
+    return np.stack(out[:n_frames], axis=0)
+
+
+@torch.no_grad()
+def infer_video_depth(sd, frames, encoder, batch_size=32, forward_fn=None):
+    """Whole-video inference on frames that are already at network size (reference: video_depth.py:67-209).
+    Returns float32 ``[N, H, W]``."""
+    n = len(frames)
+    H, W = frames[0].shape[:2]
+    plan, L, O, _ = window_plan(n, batch_size)
+    fwd = forward_fn or (lambda inp: forward(sd, inp, encoder))
+    depth_list, prev = [], None
+    for slots in plan:
+        cur = [prev[k] if kind == "prev" else torch.from_numpy(normalize_frame(frames[k])) for kind, k in slots]
+        inp = torch.stack(cur, 0).unsqueeze(0)
+        d = fwd(inp).float()
+        d = F.interpolate(d.flatten(0, 1).unsqueeze(1), size=(H, W), mode="bilinear", align_corners=True)
+        depth_list += [d[i, 0].cpu().numpy() for i in range(d.shape[0])]
+        prev = cur
+    return stitch(depth_list, n, batch_size)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# error metrics
+# ----------------------------------------------------------------------------------------------------------
+def max_rel_err(a, b):
+    """max |a-b| / max(|b|, 1e-3 max|b|): relative error with a floor, because the depth is ReLU-clamped."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    floor = 1e-3 * np.abs(b).max()
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
+
+
+def abs_rel(pred, gt):
+    """mean |gt - pred| / gt over valid pixels (reference: benchmark/eval/metric.py:3-13); valid = gt above
+    1e-3 of its maximum."""
+    pred = np.asarray(pred, dtype=np.float64)
+    gt = np.asarray(gt, dtype=np.float64)
+    m = gt > 1e-3 * gt.max()
+    return float((np.abs(gt[m] - pred[m]) / gt[m]).mean())

@@ -1,0 +1,118 @@
+"""The CPU oracle against the golden vectors captured from the unmodified reference (oracle/make_goldens.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import vda_oracle as O
+from video_depth_anything import spec
+
+TOL = 2e-5          # fp32 restatement vs fp32 reference, relative to the tensor's max magnitude
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return {k: torch.from_numpy(v) for k, v in spec.synth_state_dict(**spec.MODEL_CONFIGS["vits"], seed=1).items()}
+
+
+def frames_for(n, h, w, seed):
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = np.empty((n, h, w, 3), np.uint8)
+    for i in range(n):
+        r = (xx * 255.0 / max(w - 1, 1) + 3 * i) % 256
+        g = (yy * 255.0 / max(h - 1, 1) + 5 * i) % 256
+        b = 255 - r
+        f = np.stack([r, g, b], -1) + rs.randint(-20, 21, (h, w, 3))
+        out[i] = np.clip(f, 0, 255).astype(np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("enc", ["vits", "vitl"])
+def test_state_dict_inventory_matches_reference(golden_dir, enc):
+    want = json.load(open(os.path.join(golden_dir, f"keys_{enc}.json")))
+    got = spec.state_dict_spec(**spec.MODEL_CONFIGS[enc])
+    assert list(got.keys()) == list(want.keys())
+    for k, (shape, _) in got.items():
+        assert list(shape) == want[k], k
+    assert len(got) == {"vits": 351, "vitl": 519}[enc]
+
+
+def test_encoder_taps_and_pos_tables(golden_dir, sd):
+    g = np.load(os.path.join(golden_dir, "g1_encoder.npz"))
+    x = torch.from_numpy(np.random.RandomState(11).standard_normal((2, 3, 70, 98)).astype(np.float32))
+    taps = O.encoder_taps(sd, x, "vits")
+    for i in range(4):
+        assert rel(taps[i].numpy(), g[f"tap{i}"]) < TOL
+    for hp, wp in ((5, 7), (37, 66), (74, 74), (37, 37)):
+        pe = O.pos_embed_for(sd["pretrained.pos_embed"], hp, wp).numpy()
+        assert rel(pe[0, :, :8], g[f"pos_{hp}x{wp}"]) < 1e-6
+
+
+def test_temporal_modules(golden_dir, sd):
+    g = np.load(os.path.join(golden_dir, "g2_temporal.npz"))
+    for idx, C in ((0, 192), (2, 64), (1, 384)):
+        for T in (32, 5):
+            rs = np.random.RandomState(100 + idx * 10 + T)
+            inp = torch.from_numpy(rs.standard_normal((T, C, 3, 4)).astype(np.float32))
+            assert rel(O.temporal_module(sd, idx, inp, T).numpy(), g[f"mm{idx}_T{T}"]) < TOL
+    inp = torch.from_numpy(np.random.RandomState(199).standard_normal((8, 64, 3, 4)).astype(np.float32))
+    assert rel(O.temporal_module(sd, 3, inp, 4).numpy(), g["mm3_B2_T4"]) < TOL
+
+
+def test_head_blocks(golden_dir, sd):
+    g = np.load(os.path.join(golden_dir, "g3_head_blocks.npz"))
+    rs = np.random.RandomState(31)
+    a = torch.from_numpy(rs.standard_normal((2, 64, 5, 7)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal((2, 64, 5, 7)).astype(np.float32))
+    assert rel(O.fusion_block(sd, 3, a, b, size=(10, 14)).numpy(), g["fusion3"]) < TOL
+    assert rel(O.fusion_block(sd, 4, a, None, size=(9, 13)).numpy(), g["fusion4"]) < TOL
+    assert rel(O.fusion_block(sd, 1, a, b, size=None).numpy(), g["fusion1"]) < TOL
+
+
+@pytest.mark.parametrize("name,shape,seed", [("T32", (1, 32, 3, 70, 98), 41), ("T4", (1, 4, 3, 70, 98), 42),
+                                             ("B2T3", (2, 3, 3, 56, 42), 43), ("T32_sq", (1, 32, 3, 42, 42), 44)])
+def test_full_forward(golden_dir, sd, name, shape, seed):
+    g = np.load(os.path.join(golden_dir, "g4_forward.npz"))
+    x = torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32))
+    out = O.forward(sd, x, "vits").numpy()
+    assert out.shape == g[name].shape
+    assert rel(out, g[name]) < TOL
+
+
+@pytest.mark.parametrize("n,bs", [(1, 32), (31, 32), (32, 32), (33, 32), (33, 16), (60, 32), (60, 16), (77, 32)])
+def test_whole_video(golden_dir, sd, n, bs):
+    g = np.load(os.path.join(golden_dir, "g5_video.npz"))
+    frames = frames_for(n, 28, 42, 500 + n)
+    out = O.infer_video_depth(sd, list(frames), "vits", batch_size=bs)
+    assert out.shape == (n, 28, 42) and out.dtype == np.float32
+    assert rel(out, g[f"N{n}_bs{bs}"]) < TOL
+
+
+def test_host_tables(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g6_host.npz"))
+    for h0, w0, s, h, w in g["sizes"]:
+        assert O.network_size(int(h0), int(w0), int(s)) == (int(h), int(w))
+    s, t = O.scale_shift(np.concatenate(list(g["ls_pred"])), np.concatenate(list(g["ls_target"])))
+    assert abs(s - g["ls_out"][0]) < 1e-6 and abs(t - g["ls_out"][1]) < 1e-6
+    out = np.stack(O.blend(list(g["blend_pre"]), list(g["blend_post"])))
+    assert rel(out, g["blend_out"]) < 1e-7
+
+
+def test_vitl_width_blocks(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g7_vitl_width.npz"))
+    big = {k: torch.from_numpy(v) for k, v in spec.synth_state_dict(
+        **spec.MODEL_CONFIGS["vitl"], seed=2, only=["pretrained.blocks.3.", "head.scratch.refinenet2."]).items()}
+    tok = torch.from_numpy(np.random.RandomState(71).standard_normal((2, 40, 1024)).astype(np.float32))
+    assert rel(O.encoder_block(big, 3, tok, 16).numpy(), g["block"]) < TOL
+    rs = np.random.RandomState(72)
+    a = torch.from_numpy(rs.standard_normal((1, 256, 6, 5)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal((1, 256, 6, 5)).astype(np.float32))
+    assert rel(O.fusion_block(big, 2, a, b, size=(12, 10)).numpy(), g["fusion"]) < TOL
