@@ -1,0 +1,149 @@
+/*
+ * libvda_hip.so -- C ABI of the MI355X (gfx950) kernels behind the Video Depth Anything per-window forward pass.
+ *
+ * The reference (SidPam/Monocular-Depth-Estimation) has no native interface for this path: every operation below is
+ * a torch ATen call inside a Python nn.Module.  Each entry point cites the reference call site(s) whose arithmetic
+ * it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated or freed here;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls only enqueue work;
+ *   - return value: 0 on success, a negative VDA_E* code on a rejected argument, or the positive hipError_t of a
+ *     failed launch; nothing throws or aborts;
+ *   - "bf16" is the raw 16-bit brain-float pattern (uint16_t); activations are channels-last ("NHWC" = [frame, y, x, c]),
+ *     i.e. every feature map is a row-major [rows = frame*h*w + y*w + x, channels] matrix.
+ */
+#ifndef VDA_HIP_H
+#define VDA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDA_OK 0
+#define VDA_EINVAL (-1)   /* null pointer / non-positive size                      */
+#define VDA_ESHAPE (-2)   /* shape not supported by the kernel (alignment, range)  */
+
+/* Library identification: returns a static string "vda_hip <version> gfx950". */
+const char* vda_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM convolution on bf16 MFMA with fp32 accumulation and a fused epilogue.
+ *
+ *   acc[m][n] = sum_k A[m][k] * W[n][k]                                   (W is [N][K] row-major: torch Linear layout)
+ *   v = acc + bias[n];  v = act(v);  v *= gamma[n];  v += resid[m][n];  v += resid2[m][n];  out[m][n] = v
+ *
+ * a_mode VDA_A_CONV3 makes A an implicit im2col view of an NHWC image [img, in_h, in_w, cin] for a 3x3 convolution
+ * with padding 1 and stride `stride`: row m = output pixel (img, oy, ox), k = (tap = ky*3+kx, channel), K = 9*cin,
+ * W = [N][9][cin].  `zeros` must point to >= 256 bytes of zeros (source of the padding taps).
+ *
+ * Replaces: nn.Linear / 1x1 Conv2d / ConvTranspose2d(k == stride) / 3x3 Conv2d call sites of the reference:
+ *   patch_embed.py:76 (as GEMM over im2col rows), attention.py:51,60, mlp.py:36-39, layer_scale.py:28, block.py:105-106,
+ *   dpt.py:60-90,117-124, util/blocks.py:20-32,78-91,160, motion_module.py:113,120,123,
+ *   motion_module/attention.py:81-83,90 (via motion_module.py:242-250,290), attention.py:333,374,383-384.
+ * ------------------------------------------------------------------------------------------------------------- */
+enum { VDA_A_LINEAR = 0, VDA_A_CONV3 = 1 };
+enum { VDA_ACT_NONE = 0, VDA_ACT_GELU = 1, VDA_ACT_RELU = 2 };          /* GELU is the exact erf form            */
+enum { VDA_T_NONE = 0, VDA_T_F32 = 1, VDA_T_BF16 = 2 };
+enum {
+    VDA_EPI_PLAIN = 0,
+    VDA_EPI_GEGLU = 1,  /* W rows interleaved in blocks of 16: [val 0..15, gate 0..15, val 16..31, ...]; out has N/2
+                           columns: out = (val + b) * gelu(gate + b)   (motion_module/attention.py:382-384)        */
+    VDA_EPI_CONVT = 2,  /* ConvTranspose2d with kernel == stride == ct_k: row m = input pixel (img, y, x) of an
+                           [*, ct_h, ct_w] grid, n = (ky*ct_k + kx)*ct_c + co; the value lands at output pixel
+                           (img, y*ct_k+ky, x*ct_k+kx), channel co of an NHWC image with ct_c channels (dpt.py:71-82) */
+    VDA_EPI_DOT = 3     /* out_f32[m] = relu(sum_n relu(acc+bias)[n] * dot_w[n] + dot_b): the 3x3 conv + ReLU + 1x1
+                           conv + ReLU tail (dpt.py:119-122); needs N <= 32                                          */
+};
+
+typedef struct VdaGemmArgs {
+    const void* a;        /* bf16 [M][lda] (LINEAR) or NHWC image (CONV3)                    */
+    const void* w;        /* bf16 [N][K]                                                      */
+    void*       out;      /* out_type [.][ldc]                                                */
+    const float* bias;    /* [N] or NULL                                                      */
+    const float* gamma;   /* [N] or NULL                                                      */
+    const void* resid;    /* resid_type [M][ldr] or NULL; may alias out                        */
+    const void* resid2;   /* bf16 [M][ldr2] or NULL                                           */
+    const void* zeros;    /* >= 256 B of zeros (CONV3 only)                                    */
+    const float* dot_w;   /* [N] (EPI_DOT only)                                                */
+    float dot_b;
+    int M, N, K;          /* K % 64 == 0                                                      */
+    int lda, ldc, ldr, ldr2;
+    int a_mode, act, epi, out_type, resid_type;
+    int relu_in;          /* apply ReLU to A while loading (pre-activation conv, util/blocks.py:78) */
+    int in_h, in_w, cin, out_h, out_w, stride;   /* CONV3 geometry; cin % 64 == 0, M = imgs*out_h*out_w */
+    int ct_h, ct_w, ct_k, ct_c;                  /* EPI_CONVT geometry                                   */
+} VdaGemmArgs;
+
+int vda_gemm(const VdaGemmArgs* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Multi-head self-attention over the tokens of each frame, head dim 64, no mask, flash-style (scores never leave
+ * the CU).  qkv: bf16 [frames][n_tok][3*heads*64] laid out [q | k | v] x [head][64] as produced by the fused QKV
+ * projection, q already multiplied by 64^-1/2; out: bf16 [frames][n_tok][heads*64].
+ * Replaces attention.py:51-59 of the reference (dinov2_layers).
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Row LayerNorm (biased variance, eps inside the sqrt): fp32 rows in, bf16 rows out.
+ * Output row r reads input row (r / rows_per_group) * in_group + in_skip + r % rows_per_group, which drops the class
+ * token when taking the encoder taps (dinov2.py:310-312); with rows_per_group == in_group and in_skip == 0 it is the
+ * identity map.  If pe != NULL, pe[((r / pe_hw) % pe_T)][c] (fp32 [pe_T][C]) is added after the affine step: the
+ * temporal position table of motion_module.py:196-197 applied to rows ordered (frame, position).
+ * Replaces block.py:84,87 (norm1/norm2), dinov2.py:310, motion_module.py:166,174.
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_layernorm(const float* x, void* out, const float* weight, const float* bias, int rows, int C, float eps,
+                  int rows_per_group, int in_group, int in_skip, const float* pe, int pe_hw, int pe_T, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * GroupNorm over NHWC bf16 maps: statistics per (frame, group) over hw * C/groups values, affine, bf16 out.
+ * `work` is caller-provided scratch of frames * groups * 16 bytes, 8-byte aligned (it is zeroed by the call).
+ * Replaces motion_module.py:110.
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_groupnorm(const void* x, void* out, const float* weight, const float* bias, void* work, int frames, int hw,
+                  int C, int groups, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Bilinear resampling with align_corners=True (src = dst * (in-1)/(out-1)).
+ * vda_bilinear_nhwc: bf16 [frames][in_h][in_w][C] -> bf16 [frames][out_h][out_w][C]   (util/blocks.py:156-158,
+ *   dpt_temporal.py:94-96).  C % 8 == 0.
+ * vda_bilinear_f32: fp32 single-channel maps [frames][in_h][in_w] -> [frames][out_h][out_w], optional ReLU
+ *   (video_depth.py:63-64, 142).
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_bilinear_nhwc(const void* x, void* out, int frames, int in_h, int in_w, int out_h, int out_w, int C, void* stream);
+int vda_bilinear_f32(const float* x, float* out, int frames, int in_h, int in_w, int out_h, int out_w, int relu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Patch embedding front end.
+ * vda_im2col_patch14: fp32 NCHW frames [frames][3][H][W] -> bf16 rows [frames*hp*wp][ldk], k = c*196 + ky*14 + kx
+ *   (the flattening order of the conv weight [D][3][14][14]), columns 588..ldk-1 zero.  ldk % 64 == 0, ldk >= 588.
+ * vda_assemble_tokens: x[f][0] = cls + pos[0]; x[f][1+p] = tok[f*hw+p] + pos[1+p]  (fp32)   (dinov2.py:218-219).
+ * Replaces patch_embed.py:76-78 together with vda_gemm.
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_im2col_patch14(const float* x, void* out, int frames, int H, int W, int ldk, void* stream);
+int vda_assemble_tokens(const float* tok, const float* cls, const float* pos, float* x, int frames, int hw, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Temporal self-attention: for every (batch, spatial position, head) a softmax(q k^T * scale) v over the T <= 32
+ * frames.  qkv: bf16 rows ordered (batch, frame, position), each row [q | k | v] x [head][hd]; out: bf16 same row
+ * order, [head][hd].  Replaces motion_module.py:232,279-284,295 + motion_module/attention.py:93-111,182-211.
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_temporal_attention(const void* qkv, void* out, int batch, int T, int hw, int heads, int hd, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Window stitching (video_depth.py:166-205, utils/util.py:40-74).
+ * vda_scale_shift_sums: sums[0..4] += {sum p*p, sum p, count, sum p*t, sum t} over n fp32 values (sums is 5 doubles,
+ *   zeroed by the caller before the first call of a fit).
+ * vda_affine_blend: out = w_pre * pre + w_post * max(scale * x + shift, 0)   over n fp32 values; scale/shift are read
+ *   from device memory (ss[0], ss[1]) so no host round trip is needed; pre may be NULL when w_pre == 0.
+ * vda_solve_scale_shift: one-thread 2x2 solve in fp32 from the five sums: ss = {scale, shift} ({1,0} if det == 0).
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_scale_shift_sums(const float* pred, const float* target, double* sums, long n, void* stream);
+int vda_solve_scale_shift(const double* sums, float* ss, void* stream);
+int vda_affine_blend(const float* x, const float* pre, float* out, const float* ss, float w_pre, float w_post, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

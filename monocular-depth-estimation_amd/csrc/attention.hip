@@ -1,0 +1,169 @@
+// Flash-style multi-head self-attention for head dim 64 (see vda_attention in include/vda_hip.h).
+//
+// One workgroup = 4 waves = 128 query rows of one (frame, head); each wave owns 32 queries.  K/V tiles of 64 keys are
+// staged through registers into double-buffered LDS (loads of tile t+1 are issued before the math of tile t and
+// written to LDS after it).  Scores are computed TRANSPOSED, S^T = K Q^T with mfma_32x32x16, so that the query index
+// lives on the lane: every lane owns one query's running max / sum, the softmax needs one cross-lane exchange
+// (lane ^ 32) per tile, and the fp32 score registers, converted to bf16, are directly the B operand of the second
+// product O^T += V^T P^T (an accumulator tile reused as the next MFMA's operand; its k order is permuted and the V^T
+// operand is gathered with the same permutation by ds_read_b64_tr_b16 transposed LDS reads).
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+// byte offset of element (key row, 16-bit column col) in the V tile: 128-byte rows, the two 64-byte halves of a row
+// swapped on rows 2,3 (mod 4) so the 4 rows of a transposed 4x16 block read fall on distinct banks
+__device__ __forceinline__ int v_off(int row, int col) { return row * 128 + ((col * 2) ^ (((row >> 1) & 1) << 6)); }
+
+__global__ __launch_bounds__(256) void attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int n_tok, int heads) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int frame = blockIdx.y / heads, head = blockIdx.y % heads;
+    const int D = heads * 64, ld = 3 * D;
+    const bf16* base = qkv + (size_t)frame * n_tok * ld + head * 64;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    // Q fragments (B operand of S^T = K Q^T): lane (r, h) holds Q[q0 + r][16 ks + 8 h + 0..7]
+    bf16x8 qf[4];
+    {
+        const bf16* qrow = base + (size_t)min(q0 + r, n_tok - 1) * ld + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
+    }
+
+    // staging: thread copies 2 K pieces and 2 V pieces (16 bytes each) per tile
+    const int srow = tid >> 3, sc = tid & 7;
+    const bf16* kbase = base + D + sc * 8;
+    const bf16* vbase = base + 2 * D + sc * 8;
+    u32x4 kreg[2], vreg[2];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t row = (size_t)min(kt * 64 + i * 32 + srow, n_tok - 1) * ld;
+            kreg[i] = *reinterpret_cast<const u32x4*>(kbase + row);
+            vreg[i] = *reinterpret_cast<const u32x4*>(vbase + row);
+        }
+    };
+    auto write_tile = [&](int buf) {
+        char* kb = smem + buf * 16384;
+        char* vb = kb + 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = i * 32 + srow;
+            *reinterpret_cast<u32x4*>(kb + tile_off(row, sc)) = kreg[i];
+            *reinterpret_cast<u32x4*>(vb + v_off(row, sc * 8)) = vreg[i];
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nkt = (n_tok + 63) / 64;
+    load_tile(0);
+    write_tile(0);
+    __syncthreads();
+
+    // transposed-read lane roles inside a 16-lane group: lane 4q+p supplies row q, columns 4p..4p+3
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int tcol = 16 * ((lane >> 4) & 1) + 4 * tp;       // + 32 * db
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const char* kb = smem + cur * 16384;
+        const char* vb = kb + 8192;
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kbk][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + tile_off(32 * kbk + r, 2 * ks + h));
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kbk], 0, 0, 0);
+            }
+        }
+        if (kt == nkt - 1) {   // keys past the end of the sequence
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 64 + 32 * kbk + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= n_tok) s[kbk][i] = -INFINITY;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        const float mneg = -m_new * LOG2E;
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kbk][i], LOG2E, mneg));
+                psum += pv;
+                pf[kbk][i >> 3][i & 7] = (bf16)pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int k0 = 32 * kbk + 16 * s2 + 4 * h + tq;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (bf16x4 __attribute__((address_space(3)))*)(vb + v_off(k0, 32 * db + tcol)));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (bf16x4 __attribute__((address_space(3)))*)(vb + v_off(k0 + 8, 32 * db + tcol)));
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kbk][s2], o[db], 0, 0, 0);
+                }
+
+        if (kt + 1 < nkt) write_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + r;
+    if (q < n_tok) {
+        bf16* orow = out + ((size_t)frame * n_tok + q) * D + head * 64 + 4 * h;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16x4 v = {(bf16)(o[db][4 * g] * inv), (bf16)(o[db][4 * g + 1] * inv),
+                                  (bf16)(o[db][4 * g + 2] * inv), (bf16)(o[db][4 * g + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(orow + 32 * db + 8 * g) = v;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, void* stream) {
+    if (!qkv || !out || frames <= 0 || n_tok <= 0 || heads <= 0) return VDA_EINVAL;
+    if ((long)frames * heads > 65535) return VDA_ESHAPE;
+    dim3 grid((n_tok + 127) / 128, frames * heads);
+    hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(qkv), reinterpret_cast<bf16*>(out), n_tok, heads);
+    return hip_rc(hipGetLastError());
+}

@@ -1,0 +1,37 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, bf16 MFMA with fp32 accumulation).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vda_hip.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
+#define GLB_PTR(p) ((const void __attribute__((address_space(1)))*)(p))
+
+// 16-byte asynchronous global -> LDS copy; the LDS destination is (wave-uniform base) + lane * 16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+// Byte offset of 16-byte chunk `chunk` (0..7) of row `row` inside a [rows][64] bf16 LDS tile (128-byte rows).
+// The XOR spreads the rows a ds_read_b128 lane group touches over all 16 slots of the 256-byte bank row, for both
+// the 16-row (16x16x32) and the 32-row (32x32x16) MFMA operand fragments.
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }

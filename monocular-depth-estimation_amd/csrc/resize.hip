@@ -1,0 +1,155 @@
+// Bandwidth-bound data-movement kernels: bilinear resampling (align_corners=True), patch im2col, token assembly.
+#include "common.h"
+
+namespace {
+
+// Source index arithmetic follows ATen's upsample_bilinear2d with align_corners=True in fp32:
+// scale = (in-1)/(out-1) (0 when out == 1), src = scale * dst, i0 = (int)src, i1 = i0 + (i0 < in-1), w1 = src - i0.
+struct Lerp {
+    int i0, i1;
+    float w0, w1;
+};
+__device__ __forceinline__ Lerp lerp_of(int dst, int in, int out) {
+    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float src = scale * (float)dst;
+    Lerp l;
+    l.i0 = (int)src;
+    l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int in_h,
+                                                            int in_w, int out_h, int out_w, int C, size_t total) {
+    const int cv = C / 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * 8;
+        size_t pix = i / cv;
+        const int ox = (int)(pix % out_w);
+        pix /= out_w;
+        const int oy = (int)(pix % out_h);
+        const int f = (int)(pix / out_h);
+        const Lerp ly = lerp_of(oy, in_h, out_h), lx = lerp_of(ox, in_w, out_w);
+        const bf16* base = x + (size_t)f * in_h * in_w * C + c;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(base + ((size_t)ly.i0 * in_w + lx.i0) * C);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(base + ((size_t)ly.i0 * in_w + lx.i1) * C);
+        const bf16x8 cc = *reinterpret_cast<const bf16x8*>(base + ((size_t)ly.i1 * in_w + lx.i0) * C);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(base + ((size_t)ly.i1 * in_w + lx.i1) * C);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = ly.w0 * (lx.w0 * (float)a[k] + lx.w1 * (float)b[k]) + ly.w1 * (lx.w0 * (float)cc[k] + lx.w1 * (float)d[k]);
+            o[k] = (bf16)v;
+        }
+        *reinterpret_cast<bf16x8*>(out + i * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bilinear_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int in_h,
+                                                           int in_w, int out_h, int out_w, int relu, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % out_w);
+        size_t pix = i / out_w;
+        const int oy = (int)(pix % out_h);
+        const int f = (int)(pix / out_h);
+        const Lerp ly = lerp_of(oy, in_h, out_h), lx = lerp_of(ox, in_w, out_w);
+        const float* base = x + (size_t)f * in_h * in_w;
+        const float a = base[(size_t)ly.i0 * in_w + lx.i0], b = base[(size_t)ly.i0 * in_w + lx.i1];
+        const float c = base[(size_t)ly.i1 * in_w + lx.i0], d = base[(size_t)ly.i1 * in_w + lx.i1];
+        float v = ly.w0 * (lx.w0 * a + lx.w1 * b) + ly.w1 * (lx.w0 * c + lx.w1 * d);
+        if (relu) v = fmaxf(v, 0.f);
+        out[i] = v;
+    }
+}
+
+// One thread per 8 output columns of an im2col row.  k = c*196 + ky*14 + kx.
+__global__ __launch_bounds__(256) void im2col_patch14_kernel(const float* __restrict__ x, bf16* __restrict__ out, int H, int W,
+                                                             int hp, int wp, int ldk, size_t total) {
+    const int kv = ldk / 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k0 = (int)(i % kv) * 8;
+        size_t row = i / kv;
+        const int px = (int)(row % wp);
+        row /= wp;
+        const int py = (int)(row % hp);
+        const int f = (int)(row / hp);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            float v = 0.f;
+            if (k < 588) {
+                const int c = k / 196, rem = k - c * 196;
+                const int ky = rem / 14, kx = rem - ky * 14;
+                v = x[(((size_t)f * 3 + c) * H + py * 14 + ky) * W + px * 14 + kx];
+            }
+            o[j] = (bf16)v;
+        }
+        *reinterpret_cast<bf16x8*>(out + i * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ tok, const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, float* __restrict__ x, int hw,
+                                                              int D, size_t total) {
+    const int dv = D / 4, n_tok = hw + 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % dv) * 4;
+        const size_t row = i / dv;
+        const int t = (int)(row % n_tok);
+        const size_t f = row / n_tok;
+        f32x4 v = t == 0 ? *reinterpret_cast<const f32x4*>(cls + d)
+                         : *reinterpret_cast<const f32x4*>(tok + (f * hw + (t - 1)) * D + d);
+        v += *reinterpret_cast<const f32x4*>(pos + (size_t)t * D + d);
+        *reinterpret_cast<f32x4*>(x + i * 4) = v;
+    }
+}
+
+inline int grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int vda_bilinear_nhwc(const void* x, void* out, int frames, int in_h, int in_w, int out_h, int out_w, int C,
+                                 void* stream) {
+    if (!x || !out || frames <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || C <= 0) return VDA_EINVAL;
+    if (C % 8 != 0) return VDA_ESHAPE;
+    const size_t total = (size_t)frames * out_h * out_w * (C / 8);
+    hipLaunchKernelGGL(bilinear_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(x), reinterpret_cast<bf16*>(out), in_h, in_w, out_h, out_w, C, total);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_bilinear_f32(const float* x, float* out, int frames, int in_h, int in_w, int out_h, int out_w, int relu,
+                                void* stream) {
+    if (!x || !out || frames <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return VDA_EINVAL;
+    const size_t total = (size_t)frames * out_h * out_w;
+    hipLaunchKernelGGL(bilinear_f32_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out,
+                       in_h, in_w, out_h, out_w, relu, total);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_im2col_patch14(const float* x, void* out, int frames, int H, int W, int ldk, void* stream) {
+    if (!x || !out || frames <= 0 || H <= 0 || W <= 0) return VDA_EINVAL;
+    if (H % 14 != 0 || W % 14 != 0 || ldk % 64 != 0 || ldk < 588) return VDA_ESHAPE;
+    const int hp = H / 14, wp = W / 14;
+    const size_t total = (size_t)frames * hp * wp * (ldk / 8);
+    hipLaunchKernelGGL(im2col_patch14_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                       reinterpret_cast<bf16*>(out), H, W, hp, wp, ldk, total);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_assemble_tokens(const float* tok, const float* cls, const float* pos, float* x, int frames, int hw, int D,
+                                   void* stream) {
+    if (!tok || !cls || !pos || !x || frames <= 0 || hw <= 0 || D <= 0) return VDA_EINVAL;
+    if (D % 4 != 0) return VDA_ESHAPE;
+    const size_t total = (size_t)frames * (hw + 1) * (D / 4);
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tok,
+                       cls, pos, x, hw, D, total);
+    return hip_rc(hipGetLastError());
+}

@@ -1,0 +1,94 @@
+// Window stitching on the device: least-squares sums, 2x2 solve, affine + clamp + cross-fade (see include/vda_hip.h).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void lsq_sums_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                       double* __restrict__ sums, long n) {
+    __shared__ double red[4][4];
+    double a00 = 0, a01 = 0, b0 = 0, b1 = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double pv = p[i], tv = t[i];
+        a00 += pv * pv;
+        a01 += pv;
+        b0 += pv * tv;
+        b1 += tv;
+    }
+    double v[4] = {a00, a01, b0, b1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int k = 0; k < 4; ++k) red[wave][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        const double tot = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        // sums layout: {sum p*p, sum p, count, sum p*t, sum t}
+        const int slot = k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 3 : 4;
+        atomicAdd(&sums[slot], tot);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 4) atomicAdd(&sums[2], (double)n);
+}
+
+// The solve repeats the reference's float32 arithmetic on float32-rounded sums (utils/util.py:46-60).
+__global__ void solve_kernel(const double* __restrict__ sums, float* __restrict__ ss) {
+    const float a00 = (float)sums[0], a01 = (float)sums[1], a11 = (float)sums[2], b0 = (float)sums[3], b1 = (float)sums[4];
+    const float det = a00 * a11 - a01 * a01;
+    float x0 = 1.f, x1 = 0.f;
+    if (det != 0.f) {
+        x0 = (a11 * b0 - a01 * b1) / det;
+        x1 = (-a01 * b0 + a00 * b1) / det;
+    }
+    ss[0] = x0;
+    ss[1] = x1;
+}
+
+__global__ __launch_bounds__(256) void affine_blend_kernel(const float* __restrict__ x, const float* __restrict__ pre,
+                                                           float* __restrict__ out, const float* __restrict__ ss, float w_pre,
+                                                           float w_post, long n) {
+    const float sc = ss[0], sh = ss[1];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = x[i] * sc + sh;
+        v = v < 0.f ? 0.f : v;
+        v *= w_post;
+        if (pre) v += w_pre * pre[i];
+        out[i] = v;
+    }
+}
+
+inline int grid_for(long n) {
+    long g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int vda_scale_shift_sums(const float* pred, const float* target, double* sums, long n, void* stream) {
+    if (!pred || !target || !sums || n <= 0) return VDA_EINVAL;
+    hipLaunchKernelGGL(lsq_sums_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pred, target,
+                       sums, n);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_solve_scale_shift(const double* sums, float* ss, void* stream) {
+    if (!sums || !ss) return VDA_EINVAL;
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), sums, ss);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_affine_blend(const float* x, const float* pre, float* out, const float* ss, float w_pre, float w_post,
+                                long n, void* stream) {
+    if (!x || !out || !ss || n <= 0) return VDA_EINVAL;
+    if (w_pre != 0.f && !pre) return VDA_EINVAL;
+    hipLaunchKernelGGL(affine_blend_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                       w_pre != 0.f ? pre : nullptr, out, ss, w_pre, w_post, n);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" const char* vda_version(void) { return "vda_hip 0.1 gfx950"; }

@@ -1,0 +1,185 @@
+"""ctypes binding of libvda_hip.so (declarations: include/vda_hip.h) operating on torch CUDA(ROCm) tensors.
+
+PyTorch only supplies device memory and the stream here: every function passes raw device pointers and sizes to
+the C ABI and raises on a non-zero return code.  There is no fallback: if the library is missing, loading raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvda_hip.so")
+
+A_LINEAR, A_CONV3 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+T_NONE, T_F32, T_BF16 = 0, 1, 2
+EPI_PLAIN, EPI_GEGLU, EPI_CONVT, EPI_DOT = 0, 1, 2, 3
+
+EXPORTS = [
+    "vda_version", "vda_gemm", "vda_attention", "vda_layernorm", "vda_groupnorm", "vda_bilinear_nhwc", "vda_bilinear_f32",
+    "vda_im2col_patch14", "vda_assemble_tokens", "vda_temporal_attention", "vda_scale_shift_sums", "vda_solve_scale_shift",
+    "vda_affine_blend",
+]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("w", C.c_void_p), ("out", C.c_void_p), ("bias", C.c_void_p), ("gamma", C.c_void_p),
+        ("resid", C.c_void_p), ("resid2", C.c_void_p), ("zeros", C.c_void_p), ("dot_w", C.c_void_p), ("dot_b", C.c_float),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int), ("ldr2", C.c_int),
+        ("a_mode", C.c_int), ("act", C.c_int), ("epi", C.c_int), ("out_type", C.c_int), ("resid_type", C.c_int),
+        ("relu_in", C.c_int),
+        ("in_h", C.c_int), ("in_w", C.c_int), ("cin", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int), ("stride", C.c_int),
+        ("ct_h", C.c_int), ("ct_w", C.c_int), ("ct_k", C.c_int), ("ct_c", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: the HIP kernels are not built and there is no fallback path")
+        l = C.CDLL(LIB_PATH)
+        l.vda_version.restype = C.c_char_p
+        l.vda_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+        l.vda_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.vda_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        l.vda_groupnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_float, C.c_void_p]
+        l.vda_bilinear_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
+        l.vda_bilinear_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
+        l.vda_im2col_patch14.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.vda_assemble_tokens.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]
+        l.vda_temporal_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                             C.c_void_p]
+        l.vda_scale_shift_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+        l.vda_solve_scale_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        l.vda_affine_blend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_long,
+                                       C.c_void_p]
+        for name in EXPORTS[1:]:
+            getattr(l, name).restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}")
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libvda_hip operates on device tensors only (got a CPU tensor)")
+
+
+_zeros = {}
+
+
+def zero_page(device):
+    z = _zeros.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.uint8, device=device)
+        _zeros[device] = z
+    return z
+
+
+def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr=0, resid2=None, ldr2=0, act=ACT_NONE,
+         epi=EPI_PLAIN, relu_in=False, conv=None, convt=None, dot_w=None, dot_b=0.0):
+    """Enqueue one vda_gemm.  ``conv`` = (in_h, in_w, cin, out_h, out_w, stride); ``convt`` = (h, w, k, c)."""
+    _dev(a, w, out, bias, gamma, resid, resid2, dot_w)
+    g = GemmArgs()
+    g.a, g.w, g.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.gamma = gamma.data_ptr() if gamma is not None else None
+    g.resid = resid.data_ptr() if resid is not None else None
+    g.resid2 = resid2.data_ptr() if resid2 is not None else None
+    g.dot_w = dot_w.data_ptr() if dot_w is not None else None
+    g.dot_b = float(dot_b)
+    g.M, g.N, g.K, g.lda, g.ldc, g.ldr, g.ldr2 = M, N, K, lda, ldc, ldr, ldr2
+    g.act, g.epi, g.relu_in = act, epi, int(bool(relu_in))
+    g.out_type = T_F32 if out.dtype == torch.float32 else T_BF16
+    g.resid_type = T_NONE if resid is None else (T_F32 if resid.dtype == torch.float32 else T_BF16)
+    if conv is not None:
+        g.a_mode = A_CONV3
+        g.in_h, g.in_w, g.cin, g.out_h, g.out_w, g.stride = conv
+        g.zeros = zero_page(a.device).data_ptr()
+    else:
+        g.a_mode = A_LINEAR
+    if convt is not None:
+        g.ct_h, g.ct_w, g.ct_k, g.ct_c = convt
+    _check(lib().vda_gemm(C.byref(g), _stream()), "vda_gemm")
+
+
+def attention(qkv, out, frames, n_tok, heads):
+    _dev(qkv, out)
+    _check(lib().vda_attention(_ptr(qkv), _ptr(out), frames, n_tok, heads, _stream()), "vda_attention")
+
+
+def layernorm(x, out, weight, bias, rows, Cdim, eps, rows_per_group=None, in_group=None, in_skip=0, pe=None, pe_hw=1, pe_T=1):
+    _dev(x, out, weight, bias, pe)
+    if rows_per_group is None:
+        rows_per_group = in_group = rows
+    _check(lib().vda_layernorm(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), rows, Cdim, eps, rows_per_group, in_group,
+                               in_skip, _ptr(pe), pe_hw, pe_T, _stream()), "vda_layernorm")
+
+
+def groupnorm(x, out, weight, bias, work, frames, hw, Cdim, groups, eps):
+    _dev(x, out, weight, bias, work)
+    _check(lib().vda_groupnorm(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(work), frames, hw, Cdim, groups, eps,
+                               _stream()), "vda_groupnorm")
+
+
+def bilinear_nhwc(x, out, frames, in_h, in_w, out_h, out_w, Cdim):
+    _dev(x, out)
+    _check(lib().vda_bilinear_nhwc(_ptr(x), _ptr(out), frames, in_h, in_w, out_h, out_w, Cdim, _stream()), "vda_bilinear_nhwc")
+
+
+def bilinear_f32(x, out, frames, in_h, in_w, out_h, out_w, relu=False):
+    _dev(x, out)
+    _check(lib().vda_bilinear_f32(_ptr(x), _ptr(out), frames, in_h, in_w, out_h, out_w, int(relu), _stream()), "vda_bilinear_f32")
+
+
+def im2col_patch14(x, out, frames, H, W, ldk):
+    _dev(x, out)
+    _check(lib().vda_im2col_patch14(_ptr(x), _ptr(out), frames, H, W, ldk, _stream()), "vda_im2col_patch14")
+
+
+def assemble_tokens(tok, cls, pos, x, frames, hw, D):
+    _dev(tok, cls, pos, x)
+    _check(lib().vda_assemble_tokens(_ptr(tok), _ptr(cls), _ptr(pos), _ptr(x), frames, hw, D, _stream()), "vda_assemble_tokens")
+
+
+def temporal_attention(qkv, out, batch, T, hw, heads, hd, scale):
+    _dev(qkv, out)
+    _check(lib().vda_temporal_attention(_ptr(qkv), _ptr(out), batch, T, hw, heads, hd, scale, _stream()), "vda_temporal_attention")
+
+
+def scale_shift_sums(pred, target, sums, n):
+    _dev(pred, target, sums)
+    _check(lib().vda_scale_shift_sums(_ptr(pred), _ptr(target), _ptr(sums), n, _stream()), "vda_scale_shift_sums")
+
+
+def solve_scale_shift(sums, ss):
+    _dev(sums, ss)
+    _check(lib().vda_solve_scale_shift(_ptr(sums), _ptr(ss), _stream()), "vda_solve_scale_shift")
+
+
+def affine_blend(x, pre, out, ss, w_pre, w_post, n):
+    _dev(x, pre, out, ss)
+    _check(lib().vda_affine_blend(_ptr(x), _ptr(pre), _ptr(out), _ptr(ss), w_pre, w_post, n, _stream()), "vda_affine_blend")

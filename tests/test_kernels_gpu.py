@@ -1,0 +1,273 @@
+"""Each HIP kernel, called through the C ABI, against a plain PyTorch fp32 statement of the same operation.
+
+Inputs are rounded to bf16 first so both sides see identical operands; the tolerance then only covers fp32
+accumulation order and the final bf16 rounding of the kernel's output (2^-9 relative).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from video_depth_anything import hip  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rnd(shape, seed, scale=1.0, dtype=BF):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def close(got, want, rtol, name=""):
+    got, want = got.float(), want.float()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert err <= rtol * ref, f"{name}: max err {err:.3e} vs max ref {ref:.3e} (rtol {rtol})"
+
+
+BF_OUT = 6e-3      # bf16 output rounding (2^-8 worst case incl. accumulation noise)
+F32_OUT = 2e-5
+
+
+def test_library_loads_and_reports_version():
+    assert b"gfx950" in hip.lib().vda_version()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1370 * 2, 1152, 384), (77, 48 * 4, 1536), (513, 64, 64), (200, 32, 192)])
+def test_gemm_plain_exact_integers(M, N, K):
+    """Small-integer operands make every product and sum exact: catches any fragment/layout mix-up bit for bit."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).to(BF).to(DEV)
+    w = torch.randint(-3, 4, (N, K), generator=g).to(BF).to(DEV)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N)
+    want = a.float() @ w.float().t()
+    assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("M,N,K", [(1370, 1024, 1024), (999, 384, 1536)])
+def test_gemm_epilogue_bias_gelu_gamma_residual(M, N, K):
+    a, w = rnd((M, K), 1), rnd((N, K), 2, 1 / math.sqrt(K))
+    bias, gamma = rnd((N,), 3, 0.1, torch.float32), rnd((N,), 4, 1.0, torch.float32)
+    resid = rnd((M, N), 5, 1.0, torch.float32)
+    acc = a.float() @ w.float().t() + bias
+    out = torch.empty((M, N), dtype=BF, device=DEV)
+    hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, act=hip.ACT_GELU)
+    close(out, F.gelu(acc), BF_OUT, "gelu")
+    x = resid.clone()
+    hip.gemm(a, w, x, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, gamma=gamma, resid=x, ldr=N)     # in place on the residual
+    close(x, resid + gamma * acc, F32_OUT, "layerscale residual")
+    r16, r2 = rnd((M, N), 6), rnd((M, N), 7)
+    hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, act=hip.ACT_RELU, resid=r16, ldr=N, resid2=r2, ldr2=N)
+    close(out, F.relu(acc) + r16.float() + r2.float(), BF_OUT, "relu + 2 residuals")
+
+
+def test_gemm_geglu():
+    M, C = 700, 192
+    a, w = rnd((M, C), 1), rnd((8 * C, C), 2, 1 / math.sqrt(C))
+    bias = rnd((8 * C,), 3, 0.1, torch.float32)
+    proj = a.float() @ w.float().t() + bias
+    val, gate = proj.chunk(2, dim=-1)
+    want = val * F.gelu(gate)
+    # interleave value/gate rows in blocks of 16
+    n = 4 * C
+    wv, wg = w[:n].reshape(n // 16, 16, C), w[n:].reshape(n // 16, 16, C)
+    wi = torch.stack([wv, wg], 1).reshape(8 * C, C).contiguous()
+    bi = torch.stack([bias[:n].reshape(n // 16, 16), bias[n:].reshape(n // 16, 16)], 1).reshape(-1).contiguous()
+    out = torch.empty((M, n), dtype=BF, device=DEV)
+    hip.gemm(a, wi, out, M=M, N=8 * C, K=C, lda=C, ldc=n, bias=bi, epi=hip.EPI_GEGLU)
+    close(out, want, BF_OUT, "geglu")
+
+
+@pytest.mark.parametrize("k,C", [(4, 64), (2, 128)])
+def test_gemm_conv_transpose(k, C):
+    B, h, w_ = 3, 5, 7
+    x = rnd((B, C, h, w_), 1)
+    wt = rnd((C, C, k, k), 2, 1 / math.sqrt(C))          # [Cin, Cout, k, k]
+    bias = rnd((C,), 3, 0.1, torch.float32)
+    want = F.conv_transpose2d(x.float(), wt.float(), bias, stride=k).permute(0, 2, 3, 1)
+    a = x.permute(0, 2, 3, 1).reshape(B * h * w_, C).contiguous()
+    wg = wt.permute(2, 3, 1, 0).reshape(k * k * C, C).contiguous()       # n = (ky*k+kx)*C + co, k-dim = ci
+    out = torch.full((B, h * k, w_ * k, C), float("nan"), dtype=BF, device=DEV)
+    hip.gemm(a, wg, out, M=B * h * w_, N=k * k * C, K=C, lda=C, ldc=C, bias=bias, epi=hip.EPI_CONVT, convt=(h, w_, k, C))
+    close(out, want, BF_OUT, "convT")
+
+
+@pytest.mark.parametrize("stride,cin,cout,relu_in", [(1, 64, 64, True), (1, 128, 256, False), (2, 192, 192, False), (1, 64, 32, False)])
+def test_gemm_conv3x3(stride, cin, cout, relu_in):
+    B, h, w_ = 2, 19, 13
+    x = rnd((B, cin, h, w_), 1)
+    wt = rnd((cout, cin, 3, 3), 2, 1 / math.sqrt(9 * cin))
+    bias = rnd((cout,), 3, 0.1, torch.float32)
+    xin = F.relu(x.float()) if relu_in else x.float()
+    want = F.conv2d(xin, wt.float(), bias, stride=stride, padding=1).permute(0, 2, 3, 1)
+    oh, ow = want.shape[1], want.shape[2]
+    a = x.permute(0, 2, 3, 1).contiguous()
+    wg = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
+    out = torch.full((B, oh, ow, cout), float("nan"), dtype=BF, device=DEV)
+    hip.gemm(a, wg, out, M=B * oh * ow, N=cout, K=9 * cin, lda=0, ldc=cout, bias=bias, relu_in=relu_in,
+             conv=(h, w_, cin, oh, ow, stride))
+    close(out, want, BF_OUT, "conv3x3")
+
+
+def test_gemm_conv3x3_dot_tail():
+    B, h, w_, cin = 2, 20, 30, 64
+    x = rnd((B, cin, h, w_), 1)
+    wt = rnd((32, cin, 3, 3), 2, 1 / math.sqrt(9 * cin))
+    bias = rnd((32,), 3, 0.3, torch.float32)
+    w2 = rnd((32,), 4, 0.3, torch.float32).abs()
+    want = F.relu(F.conv2d(F.relu(F.conv2d(x.float(), wt.float(), bias, padding=1)), w2.reshape(1, 32, 1, 1), torch.tensor([0.1], device=DEV)))
+    a = x.permute(0, 2, 3, 1).contiguous()
+    wg = wt.permute(0, 2, 3, 1).reshape(32, 9 * cin).contiguous()
+    out = torch.full((B * h * w_,), float("nan"), dtype=torch.float32, device=DEV)
+    hip.gemm(a, wg, out, M=B * h * w_, N=32, K=9 * cin, lda=0, ldc=4, bias=bias, epi=hip.EPI_DOT, dot_w=w2, dot_b=0.1,
+             conv=(h, w_, cin, h, w_, 1))
+    close(out.reshape(B, 1, h, w_), want, 1e-4, "conv+dot tail")
+
+
+@pytest.mark.parametrize("frames,n_tok,heads", [(2, 1370, 6), (3, 64, 2), (1, 129, 16), (2, 36, 1)])
+def test_attention(frames, n_tok, heads):
+    D = heads * 64
+    qkv = rnd((frames, n_tok, 3 * D), 1)
+    out = torch.full((frames, n_tok, D), float("nan"), dtype=BF, device=DEV)
+    hip.attention(qkv, out, frames, n_tok, heads)
+    q, k, v = qkv.float().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    want = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(frames, n_tok, D)
+    close(out, want, 1.2e-2, "attention")       # probabilities are rounded to bf16 before the second product
+
+
+def test_attention_sharp_softmax_rescale():
+    """One key dominates from the second K/V tile on: forces the running-max rescale branch."""
+    frames, n_tok, heads = 1, 200, 1
+    qkv = rnd((frames, n_tok, 192), 2, 0.5)
+    qkv[0, 150, 64:128] = qkv[0, 10, 0:64] * 12          # key 150 aligned with query 10
+    out = torch.empty((frames, n_tok, 64), dtype=BF, device=DEV)
+    hip.attention(qkv, out, frames, n_tok, heads)
+    q, k, v = qkv.float().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    want = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(frames, n_tok, 64)
+    close(out, want, 1.2e-2, "attention rescale")
+
+
+@pytest.mark.parametrize("rows,C", [(1370 * 2, 1024), (100, 384), (37, 64), (50, 192)])
+def test_layernorm(rows, C):
+    x = rnd((rows, C), 1, 2.0, torch.float32) + 0.5
+    w, b = rnd((C,), 2, 1.0, torch.float32), rnd((C,), 3, 1.0, torch.float32)
+    out = torch.empty((rows, C), dtype=BF, device=DEV)
+    hip.layernorm(x, out, w, b, rows, C, 1e-6)
+    close(out, F.layer_norm(x, (C,), w, b, 1e-6), BF_OUT, "layernorm")
+
+
+def test_layernorm_drop_class_token_and_position_table():
+    frames, n_tok, C = 3, 36, 384
+    x = rnd((frames, n_tok, C), 1, 1.0, torch.float32)
+    w, b = rnd((C,), 2, 1.0, torch.float32), rnd((C,), 3, 1.0, torch.float32)
+    out = torch.empty((frames, n_tok - 1, C), dtype=BF, device=DEV)
+    hip.layernorm(x, out, w, b, frames * (n_tok - 1), C, 1e-6, rows_per_group=n_tok - 1, in_group=n_tok, in_skip=1)
+    close(out, F.layer_norm(x, (C,), w, b, 1e-6)[:, 1:], BF_OUT, "tap layernorm")
+    B, T, hw = 2, 5, 12
+    x = rnd((B * T, hw, C), 4, 1.0, torch.float32)
+    pe = rnd((32, C), 5, 1.0, torch.float32)
+    out = torch.empty((B * T, hw, C), dtype=BF, device=DEV)
+    hip.layernorm(x, out, w, b, B * T * hw, C, 1e-5, pe=pe, pe_hw=hw, pe_T=T)
+    want = F.layer_norm(x, (C,), w, b, 1e-5).reshape(B, T, hw, C) + pe[:T].reshape(1, T, 1, C)
+    close(out, want.reshape(B * T, hw, C), BF_OUT, "layernorm + pe")
+
+
+@pytest.mark.parametrize("frames,hw,C", [(4, 37 * 37, 256), (3, 100, 192), (2, 361, 384), (2, 50, 64)])
+def test_groupnorm(frames, hw, C):
+    x = rnd((frames, hw, C), 1, 1.5) + 0.3
+    w, b = rnd((C,), 2, 1.0, torch.float32), rnd((C,), 3, 1.0, torch.float32)
+    out = torch.empty_like(x)
+    work = torch.empty(frames * 32 * 2, dtype=torch.float64, device=DEV)
+    hip.groupnorm(x, out, w, b, work, frames, hw, C, 32, 1e-6)
+    want = F.group_norm(x.float().permute(0, 2, 1), 32, w, b, 1e-6).permute(0, 2, 1)
+    close(out, want, BF_OUT, "groupnorm")
+
+
+@pytest.mark.parametrize("ih,iw,oh,ow", [(19, 19, 37, 37), (37, 66, 74, 132), (5, 7, 10, 14), (8, 8, 14, 14), (6, 6, 6, 6)])
+def test_bilinear(ih, iw, oh, ow):
+    frames, C = 2, 64
+    x = rnd((frames, ih, iw, C), 1)
+    out = torch.empty((frames, oh, ow, C), dtype=BF, device=DEV)
+    hip.bilinear_nhwc(x, out, frames, ih, iw, oh, ow, C)
+    want = F.interpolate(x.float().permute(0, 3, 1, 2), size=(oh, ow), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    close(out, want, BF_OUT, "bilinear nhwc")
+    xf = rnd((frames, ih, iw), 2, 1.0, torch.float32)
+    of = torch.empty((frames, oh, ow), dtype=torch.float32, device=DEV)
+    hip.bilinear_f32(xf, of, frames, ih, iw, oh, ow, relu=True)
+    want = F.relu(F.interpolate(xf.unsqueeze(1), size=(oh, ow), mode="bilinear", align_corners=True)).squeeze(1)
+    close(of, want, 1e-5, "bilinear f32")
+
+
+def test_patch_embed_front_end():
+    frames, H, W, D = 2, 70, 98, 384
+    x = rnd((frames, 3, H, W), 1, 1.0, torch.float32)
+    wt = rnd((D, 3, 14, 14), 2, 1 / math.sqrt(588))
+    bias = rnd((D,), 3, 0.1, torch.float32)
+    hp, wp = H // 14, W // 14
+    cols = torch.empty((frames * hp * wp, 640), dtype=BF, device=DEV)
+    hip.im2col_patch14(x, cols, frames, H, W, 640)
+    want_cols = F.unfold(x, 14, stride=14).transpose(1, 2).reshape(frames * hp * wp, 588)
+    assert torch.equal(cols[:, :588].float(), want_cols.to(BF).float())
+    assert torch.count_nonzero(cols[:, 588:]) == 0
+    wp_ = torch.zeros((D, 640), dtype=BF, device=DEV)
+    wp_[:, :588] = wt.reshape(D, 588)
+    tok = torch.empty((frames * hp * wp, D), dtype=torch.float32, device=DEV)
+    hip.gemm(cols, wp_, tok, M=frames * hp * wp, N=D, K=640, lda=640, ldc=D, bias=bias)
+    want = F.conv2d(x.to(BF).float(), wt.float(), bias, stride=14).flatten(2).transpose(1, 2)
+    close(tok.reshape(frames, hp * wp, D), want, F32_OUT * 5, "patch embed")
+    cls, pos = rnd((D,), 4, 1.0, torch.float32), rnd((hp * wp + 1, D), 5, 1.0, torch.float32)
+    xt = torch.empty((frames, hp * wp + 1, D), dtype=torch.float32, device=DEV)
+    hip.assemble_tokens(tok, cls, pos, xt, frames, hp * wp, D)
+    want = torch.cat([cls.expand(frames, 1, D), tok.reshape(frames, hp * wp, D)], 1) + pos
+    assert torch.equal(xt, want)
+
+
+@pytest.mark.parametrize("B,T,hw,heads,hd", [(1, 32, 12, 8, 24), (2, 5, 7, 8, 48), (1, 32, 9, 8, 8), (1, 32, 10, 8, 128), (1, 4, 6, 8, 32), (1, 1, 5, 8, 8)])
+def test_temporal_attention(B, T, hw, heads, hd):
+    C = heads * hd
+    qkv = rnd((B * T * hw, 3 * C), 1)
+    out = torch.full((B * T * hw, C), float("nan"), dtype=BF, device=DEV)
+    hip.temporal_attention(qkv, out, B, T, hw, heads, hd, hd ** -0.5)
+    q, k, v = qkv.float().reshape(B, T, hw, 3, heads, hd).permute(3, 0, 2, 4, 1, 5)      # [B, hw, heads, T, hd]
+    want = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v
+    want = want.permute(0, 3, 1, 2, 4).reshape(B * T * hw, C)
+    close(out, want, BF_OUT, "temporal attention")
+
+
+def test_stitch_kernels():
+    n = 300 * 200 * 2
+    p = rnd((n,), 1, 1.0, torch.float32).abs() * 3 + 1
+    t = 1.7 * p + 0.3 + rnd((n,), 2, 0.01, torch.float32)
+    sums = torch.zeros(5, dtype=torch.float64, device=DEV)
+    hip.scale_shift_sums(p, t, sums, n)
+    pd, td = p.double(), t.double()
+    want = torch.stack([(pd * pd).sum(), pd.sum(), torch.tensor(float(n), device=DEV, dtype=torch.float64), (pd * td).sum(), td.sum()])
+    assert torch.allclose(sums, want, rtol=1e-12)
+    ss = torch.empty(2, dtype=torch.float32, device=DEV)
+    hip.solve_scale_shift(sums, ss)
+    assert abs(ss[0].item() - 1.7) < 1e-3 and abs(ss[1].item() - 0.3) < 3e-3
+    x, pre = rnd((n,), 3, 1.0, torch.float32), rnd((n,), 4, 1.0, torch.float32)
+    out = torch.empty_like(x)
+    hip.affine_blend(x, pre, out, ss, 0.25, 0.75, n)
+    want = 0.25 * pre + 0.75 * torch.clamp(x * ss[0] + ss[1], min=0)
+    assert torch.allclose(out, want, rtol=1e-6, atol=1e-6)
+    hip.affine_blend(x, None, out, ss, 0.0, 1.0, n)
+    assert torch.allclose(out, torch.clamp(x * ss[0] + ss[1], min=0), rtol=1e-6, atol=1e-6)
+
+
+def test_rejected_arguments_return_error_codes():
+    a = torch.zeros((128, 96), dtype=BF, device=DEV)
+    w = torch.zeros((128, 96), dtype=BF, device=DEV)
+    out = torch.zeros((128, 128), dtype=BF, device=DEV)
+    with pytest.raises(RuntimeError):
+        hip.gemm(a, w, out, M=128, N=128, K=96, lda=96, ldc=128)        # K not a multiple of 64
+    with pytest.raises(RuntimeError):
+        hip.gemm(a.cpu(), w, out, M=128, N=128, K=64, lda=96, ldc=128)  # host pointer
+    with pytest.raises(RuntimeError):
+        hip.temporal_attention(a, out, 1, 33, 1, 8, 8, 1.0)              # T > 32
