@@ -28,7 +28,8 @@ extern "C" {
 const char* vda_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * GEMM / implicit-GEMM convolution on bf16 MFMA with fp32 accumulation and a fused epilogue.
+ * GEMM / implicit-GEMM convolution on 16-bit MFMA (operands bf16 or fp16, selected by ab_type; same matrix-core
+ * rate) with fp32 accumulation and a fused epilogue.
  *
  *   acc[m][n] = sum_k A[m][k] * W[n][k]                                   (W is [N][K] row-major: torch Linear layout)
  *   v = acc + bias[n];  v = act(v);  v *= gamma[n];  v += resid[m][n];  v += resid2[m][n];  out[m][n] = v
@@ -44,7 +45,7 @@ const char* vda_version(void);
  * ------------------------------------------------------------------------------------------------------------- */
 enum { VDA_A_LINEAR = 0, VDA_A_CONV3 = 1 };
 enum { VDA_ACT_NONE = 0, VDA_ACT_GELU = 1, VDA_ACT_RELU = 2 };          /* GELU is the exact erf form            */
-enum { VDA_T_NONE = 0, VDA_T_F32 = 1, VDA_T_BF16 = 2 };
+enum { VDA_T_NONE = 0, VDA_T_F32 = 1, VDA_T_BF16 = 2, VDA_T_F16 = 3 };   /* "half" below = BF16 or F16 (IEEE half)  */
 enum {
     VDA_EPI_PLAIN = 0,
     VDA_EPI_GEGLU = 1,  /* W rows interleaved in blocks of 16: [val 0..15, gate 0..15, val 16..31, ...]; out has N/2
@@ -57,19 +58,20 @@ enum {
 };
 
 typedef struct VdaGemmArgs {
-    const void* a;        /* bf16 [M][lda] (LINEAR) or NHWC image (CONV3)                    */
-    const void* w;        /* bf16 [N][K]                                                      */
+    const void* a;        /* half [M][lda] (LINEAR) or NHWC image (CONV3)                    */
+    const void* w;        /* half [N][K]                                                      */
     void*       out;      /* out_type [.][ldc]                                                */
     const float* bias;    /* [N] or NULL                                                      */
     const float* gamma;   /* [N] or NULL                                                      */
     const void* resid;    /* resid_type [M][ldr] or NULL; may alias out                        */
-    const void* resid2;   /* bf16 [M][ldr2] or NULL                                           */
+    const void* resid2;   /* ab_type [M][ldr2] or NULL                                        */
     const void* zeros;    /* >= 256 B of zeros (CONV3 only)                                    */
     const float* dot_w;   /* [N] (EPI_DOT only)                                                */
     float dot_b;
     int M, N, K;          /* K % 64 == 0                                                      */
     int lda, ldc, ldr, ldr2;
     int a_mode, act, epi, out_type, resid_type;
+    int ab_type;          /* VDA_T_BF16 or VDA_T_F16: element type of a, w and resid2          */
     int relu_in;          /* apply ReLU to A while loading (pre-activation conv, util/blocks.py:78) */
     int in_h, in_w, cin, out_h, out_w, stride;   /* CONV3 geometry; cin % 64 == 0, M = imgs*out_h*out_w */
     int ct_h, ct_w, ct_k, ct_c;                  /* EPI_CONVT geometry                                   */
@@ -86,7 +88,7 @@ int vda_gemm(const VdaGemmArgs* args, void* stream);
 int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * Row LayerNorm (biased variance, eps inside the sqrt): fp32 rows in, bf16 rows out.
+ * Row LayerNorm (biased variance, eps inside the sqrt): fp32 rows in, half rows out (out_type BF16 or F16).
  * Output row r reads input row (r / rows_per_group) * in_group + in_skip + r % rows_per_group, which drops the class
  * token when taking the encoder taps (dinov2.py:310-312); with rows_per_group == in_group and in_skip == 0 it is the
  * identity map.  If pe != NULL, pe[((r / pe_hw) % pe_T)][c] (fp32 [pe_T][C]) is added after the affine step: the
@@ -94,24 +96,27 @@ int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, 
  * Replaces block.py:84,87 (norm1/norm2), dinov2.py:310, motion_module.py:166,174.
  * ------------------------------------------------------------------------------------------------------------- */
 int vda_layernorm(const float* x, void* out, const float* weight, const float* bias, int rows, int C, float eps,
-                  int rows_per_group, int in_group, int in_skip, const float* pe, int pe_hw, int pe_T, void* stream);
+                  int rows_per_group, int in_group, int in_skip, const float* pe, int pe_hw, int pe_T, int out_type,
+                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * GroupNorm over NHWC bf16 maps: statistics per (frame, group) over hw * C/groups values, affine, bf16 out.
+ * GroupNorm over NHWC half maps (dtype BF16 or F16): statistics per (frame, group) over hw * C/groups values, affine,
+ * output in the same type.
  * `work` is caller-provided scratch of frames * groups * 16 bytes, 8-byte aligned (it is zeroed by the call).
  * Replaces motion_module.py:110.
  * ------------------------------------------------------------------------------------------------------------- */
 int vda_groupnorm(const void* x, void* out, const float* weight, const float* bias, void* work, int frames, int hw,
-                  int C, int groups, float eps, void* stream);
+                  int C, int groups, float eps, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Bilinear resampling with align_corners=True (src = dst * (in-1)/(out-1)).
- * vda_bilinear_nhwc: bf16 [frames][in_h][in_w][C] -> bf16 [frames][out_h][out_w][C]   (util/blocks.py:156-158,
+ * vda_bilinear_nhwc: half [frames][in_h][in_w][C] -> half [frames][out_h][out_w][C] (dtype BF16 or F16)   (util/blocks.py:156-158,
  *   dpt_temporal.py:94-96).  C % 8 == 0.
  * vda_bilinear_f32: fp32 single-channel maps [frames][in_h][in_w] -> [frames][out_h][out_w], optional ReLU
  *   (video_depth.py:63-64, 142).
  * ------------------------------------------------------------------------------------------------------------- */
-int vda_bilinear_nhwc(const void* x, void* out, int frames, int in_h, int in_w, int out_h, int out_w, int C, void* stream);
+int vda_bilinear_nhwc(const void* x, void* out, int frames, int in_h, int in_w, int out_h, int out_w, int C, int dtype,
+                      void* stream);
 int vda_bilinear_f32(const float* x, float* out, int frames, int in_h, int in_w, int out_h, int out_w, int relu, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -125,11 +130,19 @@ int vda_im2col_patch14(const float* x, void* out, int frames, int H, int W, int 
 int vda_assemble_tokens(const float* tok, const float* cls, const float* pos, float* x, int frames, int hw, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * Temporal self-attention: for every (batch, spatial position, head) a softmax(q k^T * scale) v over the T <= 32
- * frames.  qkv: bf16 rows ordered (batch, frame, position), each row [q | k | v] x [head][hd]; out: bf16 same row
- * order, [head][hd].  Replaces motion_module.py:232,279-284,295 + motion_module/attention.py:93-111,182-211.
+ * Frame preprocessing: uint8 RGB frames [frames][h0][w0][3] -> fp32 [frames][3][H][W]: x/255, bicubic resize with
+ * OpenCV INTER_CUBIC semantics (half-pixel centres, A = -0.75, replicated border; identity when sizes match), ImageNet
+ * mean/std normalisation, HWC -> CHW.  Replaces video_depth.py:120 + util/transform.py:109-158 (cv2.resize).
  * ------------------------------------------------------------------------------------------------------------- */
-int vda_temporal_attention(const void* qkv, void* out, int batch, int T, int hw, int heads, int hd, float scale, void* stream);
+int vda_preprocess_u8(const uint8_t* frames_u8, float* out, int frames, int h0, int w0, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Temporal self-attention: for every (batch, spatial position, head) a softmax(q k^T * scale) v over the T <= 32
+ * frames.  qkv: half rows ordered (batch, frame, position), each row [q | k | v] x [head][hd]; out: half, same row
+ * order, [head][hd] (dtype BF16 or F16 for both).  Replaces motion_module.py:232,279-284,295 + motion_module/attention.py:93-111,182-211.
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_temporal_attention(const void* qkv, void* out, int batch, int T, int hw, int heads, int hd, float scale, int dtype,
+                           void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Window stitching (video_depth.py:166-205, utils/util.py:40-74).

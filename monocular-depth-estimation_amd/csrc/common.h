@@ -8,6 +8,9 @@ typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -33,5 +36,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// 16-bit storage types: vectors of 4 / 8 elements per type
+template <typename T> struct Vec;
+template <> struct Vec<bf16> { typedef bf16x4 v4; typedef bf16x8 v8; };
+template <> struct Vec<f16> { typedef f16x4 v4; typedef f16x8 v8; };
 
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }

@@ -19,24 +19,41 @@ struct GemmTiles {
 
 typedef short short8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ bf16x8 relu8(bf16x8 v) {
-    // bf16 sign bit == int16 sign bit, so max(int16, 0) is ReLU (and maps -0.0 to +0.0)
+template <typename V8>
+__device__ __forceinline__ V8 relu8(V8 v) {
+    // the float sign bit is the int16 sign bit, so max(int16, 0) is ReLU for bf16 and fp16 (and maps -0.0 to +0.0)
     short8 s = __builtin_bit_cast(short8, v);
     short8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     s = __builtin_elementwise_max(s, z);
-    return __builtin_bit_cast(bf16x8, s);
+    return __builtin_bit_cast(V8, s);
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ f32x4 load4(const void* p, int type, size_t idx) {
+    if (type == VDA_T_F32) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + idx);
+    if (type == VDA_T_BF16) {
+        const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p) + idx);
+        return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+    }
+    const f16x4 r = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(p) + idx);
+    return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
 }
 
 __device__ __forceinline__ void store4(void* out, int out_type, size_t idx, f32x4 v) {
     if (out_type == VDA_T_F32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + idx) = v;
-    } else {
+    } else if (out_type == VDA_T_BF16) {
         bf16x4 b = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
         *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(out) + idx) = b;
+    } else {
+        f16x4 b = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(out) + idx) = b;
     }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE>
+template <int BM, int BN, int WM, int WN, int AMODE, typename T>
 __global__ __launch_bounds__(256) void gemm_kernel(const VdaGemmArgs p, const GemmTiles gt) {
     constexpr int TM = BM / WM / 16;      // 16x16 MFMA tiles per wave along M
     constexpr int TN = BN / WN / 16;
@@ -44,6 +61,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const VdaGemmArgs p, const Ge
     constexpr int NB = BN / 32;
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BN * 128;
+    typedef typename Vec<T>::v8 frag_t;
+    // the staging below only moves 16-bit patterns, so its pointer arithmetic uses bf16* for either operand type
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -139,16 +158,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const VdaGemmArgs p, const Ge
         const char* bbuf = abuf + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[TM], wf[TN];
+            frag_t af[TM], wf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = wm * (BM / WM) + i * 16 + frow;
-                af[i] = *reinterpret_cast<const bf16x8*>(abuf + tile_off(row, ks * 4 + fq));
+                af[i] = *reinterpret_cast<const frag_t*>(abuf + tile_off(row, ks * 4 + fq));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn * (BN / WN) + j * 16 + frow;
-                wf[j] = *reinterpret_cast<const bf16x8*>(bbuf + tile_off(row, ks * 4 + fq));
+                wf[j] = *reinterpret_cast<const frag_t*>(bbuf + tile_off(row, ks * 4 + fq));
             }
             if (p.relu_in) {
 #pragma unroll
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const VdaGemmArgs p, const Ge
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
         }
         __syncthreads();   // also drains the in-flight copy of step kt+1 (vmcnt(0) precedes the barrier)
     }
@@ -244,18 +263,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const VdaGemmArgs p, const Ge
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             v *= g;
-            if (p.resid_type == VDA_T_F32) {
-                v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.resid) + (size_t)m * p.ldr + n);
-            } else if (p.resid_type == VDA_T_BF16) {
-                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.resid) + (size_t)m * p.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-            }
-            if (p.resid2) {
-                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.resid2) + (size_t)m * p.ldr2 + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-            }
+            if (p.resid_type != VDA_T_NONE) v += load4(p.resid, p.resid_type, (size_t)m * p.ldr + n);
+            if (p.resid2) v += load4(p.resid2, p.ab_type, (size_t)m * p.ldr2 + n);
             size_t idx;
             if (p.epi == VDA_EPI_CONVT) {
                 const int iy = m / p.ct_w, x = m - iy * p.ct_w;     // iy = img * ct_h + y
@@ -268,21 +277,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const VdaGemmArgs p, const Ge
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch(const VdaGemmArgs& a, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, typename T>
+int launch_t(const VdaGemmArgs& a, hipStream_t s) {
     GemmTiles gt{(a.M + BM - 1) / BM, (a.N + BN - 1) / BN};
     const int lds = 2 * (BM + BN) * 128;
     dim3 grid(gt.tiles_m * gt.tiles_n);
     if (a.a_mode == VDA_A_CONV3) {
-        auto k = gemm_kernel<BM, BN, WM, WN, VDA_A_CONV3>;
+        auto k = gemm_kernel<BM, BN, WM, WN, VDA_A_CONV3, T>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, gt);
     } else {
-        auto k = gemm_kernel<BM, BN, WM, WN, VDA_A_LINEAR>;
+        auto k = gemm_kernel<BM, BN, WM, WN, VDA_A_LINEAR, T>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, gt);
     }
     return hip_rc(hipGetLastError());
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const VdaGemmArgs& a, hipStream_t s) {
+    return a.ab_type == VDA_T_F16 ? launch_t<BM, BN, WM, WN, f16>(a, s) : launch_t<BM, BN, WM, WN, bf16>(a, s);
 }
 
 }  // namespace
@@ -313,7 +327,8 @@ extern "C" int vda_gemm(const VdaGemmArgs* args, void* stream) {
     } else if (a.epi != VDA_EPI_PLAIN) {
         return VDA_EINVAL;
     }
-    if (a.out_type != VDA_T_F32 && a.out_type != VDA_T_BF16) return VDA_EINVAL;
+    if (a.out_type != VDA_T_F32 && a.out_type != VDA_T_BF16 && a.out_type != VDA_T_F16) return VDA_EINVAL;
+    if (a.ab_type != VDA_T_BF16 && a.ab_type != VDA_T_F16) return VDA_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (a.N <= 32) return launch<128, 32, 4, 1>(a, s);
     if (a.N <= 64) return launch<128, 64, 2, 2>(a, s);

@@ -1,4 +1,4 @@
-// Bandwidth-bound normalisation kernels: row LayerNorm (fp32 -> bf16) and NHWC GroupNorm (bf16 -> bf16).
+// Bandwidth-bound normalisation kernels: row LayerNorm (fp32 -> bf16/fp16) and NHWC GroupNorm (16-bit in and out).
 // Every global access is a 16-byte (LayerNorm) or 8/16-byte (GroupNorm) vector per lane; statistics are two-pass in
 // registers (LayerNorm) or fp32 partials combined in double (GroupNorm).
 #include "common.h"
@@ -6,8 +6,8 @@
 namespace {
 
 // One wave per row, C <= 64 * 4 * VEC4 floats.  C % 4 == 0.
-template <int VEC4>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, bf16* __restrict__ out,
+template <int VEC4, typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, T* __restrict__ out,
                                                         const float* __restrict__ w, const float* __restrict__ b, int rows,
                                                         int C, float eps, int rows_per_group, int in_group, int in_skip,
                                                         const float* __restrict__ pe, int pe_hw, int pe_T) {
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     const float rstd = rsqrtf(wave_sum(q) / C + eps);
     const float* per = pe ? pe + (size_t)((row / pe_hw) % pe_T) * C : nullptr;
-    bf16* orow = out + (size_t)row * C;
+    T* orow = out + (size_t)row * C;
 #pragma unroll
     for (int i = 0; i < VEC4; ++i) {
         const int c = (i * 64 + lane) * 4;
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
             f32x4 y = (v[i] - mean) * rstd * ww + bb;
             if (per) y += *reinterpret_cast<const f32x4*>(per + c);
-            const bf16x4 o = {(bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
-            *reinterpret_cast<bf16x4*>(orow + c) = o;
+            const typename Vec<T>::v4 o = {(T)y[0], (T)y[1], (T)y[2], (T)y[3]};
+            *reinterpret_cast<typename Vec<T>::v4*>(orow + c) = o;
         }
     }
 }
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // GroupNorm pass 1: grid (frames, splits).  Each block walks a slice of the frame's pixels; thread t owns the 8
 // channels [8*(t % (C/8)) ..] (so a thread stays inside one group when C/groups is even and >= ... see host check),
 // partial sums go to LDS per group, then one double atomicAdd pair per (frame, group, block).
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16* __restrict__ x, double* __restrict__ sums, int hw,
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, double* __restrict__ sums, int hw,
                                                               int C, int groups) {
     __shared__ float red[2 * 64];
     const int frame = blockIdx.x;
@@ -68,11 +69,11 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16* __rest
     if (threadIdx.x < 2 * groups) red[threadIdx.x] = 0.f;
     __syncthreads();
     const size_t total = (size_t)hw * cv;
-    const bf16* xf = x + (size_t)frame * hw * C;
+    const T* xf = x + (size_t)frame * hw * C;
     // a thread's vector index advances by a multiple of cv?  Not in general, so recompute the group per element.
     for (size_t i = (size_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.y * blockDim.x) {
         const int c0 = (int)(i % cv) * 8;
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(xf + i * 8);
+        const typename Vec<T>::v8 v = *reinterpret_cast<const typename Vec<T>::v8*>(xf + i * 8);
         if (cpg % 8 == 0) {
             float s = 0.f, q = 0.f;
 #pragma unroll
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16* __rest
     if (threadIdx.x < 2 * groups) atomicAdd(&sums[(size_t)frame * 2 * groups + threadIdx.x], (double)red[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16* __restrict__ x, bf16* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                               const float* __restrict__ w, const float* __restrict__ b,
                                                               const double* __restrict__ sums, int hw, int C, int groups,
                                                               float eps) {
@@ -111,18 +113,18 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16* __rest
     __syncthreads();
     const int cv = C / 8;
     const size_t total = (size_t)hw * cv;
-    const bf16* xf = x + (size_t)frame * hw * C;
-    bf16* of = out + (size_t)frame * hw * C;
+    const T* xf = x + (size_t)frame * hw * C;
+    T* of = out + (size_t)frame * hw * C;
     for (size_t i = (size_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.y * blockDim.x) {
         const int c0 = (int)(i % cv) * 8;
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(xf + i * 8);
-        bf16x8 o;
+        const typename Vec<T>::v8 v = *reinterpret_cast<const typename Vec<T>::v8*>(xf + i * 8);
+        typename Vec<T>::v8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int g = (c0 + k) / cpg;
-            o[k] = (bf16)(((float)v[k] - mean_s[g]) * rstd_s[g] * w[c0 + k] + b[c0 + k]);
+            o[k] = (T)(((float)v[k] - mean_s[g]) * rstd_s[g] * w[c0 + k] + b[c0 + k]);
         }
-        *reinterpret_cast<bf16x8*>(of + i * 8) = o;
+        *reinterpret_cast<typename Vec<T>::v8*>(of + i * 8) = o;
     }
 }
 
@@ -130,16 +132,22 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16* __rest
 
 extern "C" int vda_layernorm(const float* x, void* out, const float* weight, const float* bias, int rows, int C, float eps,
                              int rows_per_group, int in_group, int in_skip, const float* pe, int pe_hw, int pe_T,
-                             void* stream) {
+                             int out_type, void* stream) {
     if (!x || !out || !weight || !bias || rows <= 0 || C <= 0) return VDA_EINVAL;
     if (C % 4 != 0 || C > 2048 || rows_per_group <= 0 || in_group < rows_per_group + in_skip) return VDA_ESHAPE;
     if (pe && (pe_hw <= 0 || pe_T <= 0)) return VDA_EINVAL;
+    if (out_type != VDA_T_BF16 && out_type != VDA_T_F16) return VDA_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((rows + 3) / 4), block(256);
-    bf16* o = reinterpret_cast<bf16*>(out);
-#define LN_LAUNCH(V)                                                                                                  \
-    hipLaunchKernelGGL(layernorm_kernel<V>, grid, block, 0, s, x, o, weight, bias, rows, C, eps, rows_per_group, in_group, \
-                       in_skip, pe, pe_hw, pe_T)
+#define LN_LAUNCH(V)                                                                                                       \
+    do {                                                                                                                   \
+        if (out_type == VDA_T_F16)                                                                                         \
+            hipLaunchKernelGGL((layernorm_kernel<V, f16>), grid, block, 0, s, x, reinterpret_cast<f16*>(out), weight, bias, \
+                               rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T);                          \
+        else                                                                                                               \
+            hipLaunchKernelGGL((layernorm_kernel<V, bf16>), grid, block, 0, s, x, reinterpret_cast<bf16*>(out), weight,    \
+                               bias, rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T);                    \
+    } while (0)
     if (C <= 256) LN_LAUNCH(1);
     else if (C <= 512) LN_LAUNCH(2);
     else if (C <= 1024) LN_LAUNCH(4);
@@ -149,10 +157,11 @@ extern "C" int vda_layernorm(const float* x, void* out, const float* weight, con
 }
 
 extern "C" int vda_groupnorm(const void* x, void* out, const float* weight, const float* bias, void* work, int frames,
-                             int hw, int C, int groups, float eps, void* stream) {
+                             int hw, int C, int groups, float eps, int dtype, void* stream) {
     if (!x || !out || !weight || !bias || !work || frames <= 0 || hw <= 0) return VDA_EINVAL;
     if (groups <= 0 || groups > 64 || C % groups != 0 || C % 8 != 0) return VDA_ESHAPE;
     if (((uintptr_t)work & 7) != 0) return VDA_ESHAPE;
+    if (dtype != VDA_T_BF16 && dtype != VDA_T_F16) return VDA_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     double* sums = reinterpret_cast<double*>(work);
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * groups * frames, s);
@@ -162,8 +171,14 @@ extern "C" int vda_groupnorm(const void* x, void* out, const float* weight, cons
     if (splits > 64) splits = 64;
     if (splits < 1) splits = 1;
     dim3 grid(frames, splits);
-    hipLaunchKernelGGL(groupnorm_stats_kernel, grid, dim3(256), 0, s, reinterpret_cast<const bf16*>(x), sums, hw, C, groups);
-    hipLaunchKernelGGL(groupnorm_apply_kernel, grid, dim3(256), 0, s, reinterpret_cast<const bf16*>(x),
-                       reinterpret_cast<bf16*>(out), weight, bias, sums, hw, C, groups, eps);
+    if (dtype == VDA_T_F16) {
+        hipLaunchKernelGGL(groupnorm_stats_kernel<f16>, grid, dim3(256), 0, s, reinterpret_cast<const f16*>(x), sums, hw, C, groups);
+        hipLaunchKernelGGL(groupnorm_apply_kernel<f16>, grid, dim3(256), 0, s, reinterpret_cast<const f16*>(x),
+                           reinterpret_cast<f16*>(out), weight, bias, sums, hw, C, groups, eps);
+    } else {
+        hipLaunchKernelGGL(groupnorm_stats_kernel<bf16>, grid, dim3(256), 0, s, reinterpret_cast<const bf16*>(x), sums, hw, C, groups);
+        hipLaunchKernelGGL(groupnorm_apply_kernel<bf16>, grid, dim3(256), 0, s, reinterpret_cast<const bf16*>(x),
+                           reinterpret_cast<bf16*>(out), weight, bias, sums, hw, C, groups, eps);
+    }
     return hip_rc(hipGetLastError());
 }

@@ -20,7 +20,8 @@ __device__ __forceinline__ Lerp lerp_of(int dst, int in, int out) {
     return l;
 }
 
-__global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int in_h,
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const T* __restrict__ x, T* __restrict__ out, int in_h,
                                                             int in_w, int out_h, int out_w, int C, size_t total) {
     const int cv = C / 8;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -31,18 +32,19 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const bf16* __restri
         const int oy = (int)(pix % out_h);
         const int f = (int)(pix / out_h);
         const Lerp ly = lerp_of(oy, in_h, out_h), lx = lerp_of(ox, in_w, out_w);
-        const bf16* base = x + (size_t)f * in_h * in_w * C + c;
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(base + ((size_t)ly.i0 * in_w + lx.i0) * C);
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(base + ((size_t)ly.i0 * in_w + lx.i1) * C);
-        const bf16x8 cc = *reinterpret_cast<const bf16x8*>(base + ((size_t)ly.i1 * in_w + lx.i0) * C);
-        const bf16x8 d = *reinterpret_cast<const bf16x8*>(base + ((size_t)ly.i1 * in_w + lx.i1) * C);
-        bf16x8 o;
+        typedef typename Vec<T>::v8 v8;
+        const T* base = x + (size_t)f * in_h * in_w * C + c;
+        const v8 a = *reinterpret_cast<const v8*>(base + ((size_t)ly.i0 * in_w + lx.i0) * C);
+        const v8 b = *reinterpret_cast<const v8*>(base + ((size_t)ly.i0 * in_w + lx.i1) * C);
+        const v8 cc = *reinterpret_cast<const v8*>(base + ((size_t)ly.i1 * in_w + lx.i0) * C);
+        const v8 d = *reinterpret_cast<const v8*>(base + ((size_t)ly.i1 * in_w + lx.i1) * C);
+        v8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float v = ly.w0 * (lx.w0 * (float)a[k] + lx.w1 * (float)b[k]) + ly.w1 * (lx.w0 * (float)cc[k] + lx.w1 * (float)d[k]);
-            o[k] = (bf16)v;
+            o[k] = (T)v;
         }
-        *reinterpret_cast<bf16x8*>(out + i * 8) = o;
+        *reinterpret_cast<v8*>(out + i * 8) = o;
     }
 }
 
@@ -106,6 +108,58 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __res
     }
 }
 
+
+// Frame preprocessing: uint8 RGB HWC -> (x/255) -> bicubic resize -> ImageNet normalisation -> fp32 CHW.
+// The resize follows OpenCV's INTER_CUBIC on float32 images: src = (dst + 0.5) * (in/out) - 0.5, Keys kernel with
+// A = -0.75 (4th coefficient = 1 - the other three), source indices clamped to the border, horizontal pass then
+// vertical pass in float32.  With in == out it is the identity.
+__device__ __forceinline__ void cv_cubic(int dst, int in, int out, int& i0, float w[4]) {
+    const double scale = (double)in / (double)out;
+    float f = (float)((dst + 0.5) * scale - 0.5);
+    const int s = (int)floorf(f);
+    f -= (float)s;
+    const float A = -0.75f;
+    w[0] = ((A * (f + 1.f) - 5.f * A) * (f + 1.f) + 8.f * A) * (f + 1.f) - 4.f * A;
+    w[1] = ((A + 2.f) * f - (A + 3.f)) * f * f + 1.f;
+    w[2] = ((A + 2.f) * (1.f - f) - (A + 3.f)) * (1.f - f) * (1.f - f) + 1.f;
+    w[3] = 1.f - w[0] - w[1] - w[2];
+    i0 = s - 1;
+}
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int h0,
+                                                         int w0, int H, int W, size_t total) {
+    const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        size_t r = i / W;
+        const int y = (int)(r % H);
+        const size_t f = r / H;
+        int ix0, iy0;
+        float wx[4], wy[4];
+        cv_cubic(x, w0, W, ix0, wx);
+        cv_cubic(y, h0, H, iy0, wy);
+        const uint8_t* img = src + f * (size_t)h0 * w0 * 3;
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const int yy = min(max(iy0 + ky, 0), h0 - 1);
+            float row[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const int xx = min(max(ix0 + kx, 0), w0 - 1);
+                const uint8_t* px = img + ((size_t)yy * w0 + xx) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) row[c] += wx[kx] * ((float)px[c] / 255.0f);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] += wy[ky] * row[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            dst[((f * 3 + c) * H + y) * (size_t)W + x] = (float)(((double)acc[c] - mean[c]) / stdv[c]);
+    }
+}
+
 inline int grid_for(size_t total) {
     size_t g = (total + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
@@ -116,12 +170,18 @@ inline int grid_for(size_t total) {
 }  // namespace
 
 extern "C" int vda_bilinear_nhwc(const void* x, void* out, int frames, int in_h, int in_w, int out_h, int out_w, int C,
-                                 void* stream) {
+                                 int dtype, void* stream) {
     if (!x || !out || frames <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || C <= 0) return VDA_EINVAL;
     if (C % 8 != 0) return VDA_ESHAPE;
+    if (dtype != VDA_T_BF16 && dtype != VDA_T_F16) return VDA_EINVAL;
     const size_t total = (size_t)frames * out_h * out_w * (C / 8);
-    hipLaunchKernelGGL(bilinear_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const bf16*>(x), reinterpret_cast<bf16*>(out), in_h, in_w, out_h, out_w, C, total);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == VDA_T_F16)
+        hipLaunchKernelGGL(bilinear_nhwc_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, reinterpret_cast<const f16*>(x),
+                           reinterpret_cast<f16*>(out), in_h, in_w, out_h, out_w, C, total);
+    else
+        hipLaunchKernelGGL(bilinear_nhwc_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, reinterpret_cast<const bf16*>(x),
+                           reinterpret_cast<bf16*>(out), in_h, in_w, out_h, out_w, C, total);
     return hip_rc(hipGetLastError());
 }
 
@@ -151,5 +211,13 @@ extern "C" int vda_assemble_tokens(const float* tok, const float* cls, const flo
     const size_t total = (size_t)frames * (hw + 1) * (D / 4);
     hipLaunchKernelGGL(assemble_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tok,
                        cls, pos, x, hw, D, total);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_preprocess_u8(const uint8_t* frames_u8, float* out, int frames, int h0, int w0, int H, int W, void* stream) {
+    if (!frames_u8 || !out || frames <= 0 || h0 <= 0 || w0 <= 0 || H <= 0 || W <= 0) return VDA_EINVAL;
+    const size_t total = (size_t)frames * H * W;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), frames_u8,
+                       out, h0, w0, H, W, total);
     return hip_rc(hipGetLastError());
 }

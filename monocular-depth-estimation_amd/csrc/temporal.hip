@@ -9,32 +9,33 @@
 
 namespace {
 
-template <int HD>
-__global__ __launch_bounds__(64) void temporal_attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T,
+template <int HD, typename T16>
+__global__ __launch_bounds__(64) void temporal_attn_kernel(const T16* __restrict__ qkv, T16* __restrict__ out, int T,
                                                            int hw, int heads, float scale_log2e) {
     constexpr int HH = HD / 2;
     constexpr int V4 = HH / 4;
-    __shared__ __attribute__((aligned(16))) bf16 ks[32 * HD];
-    __shared__ __attribute__((aligned(16))) bf16 vs[32 * HD];
+    typedef typename Vec<T16>::v4 v4_t;
+    __shared__ __attribute__((aligned(16))) T16 ks[32 * HD];
+    __shared__ __attribute__((aligned(16))) T16 vs[32 * HD];
     const int lane = threadIdx.x, t = lane & 31, half = lane >> 5;
     const int head = blockIdx.x % heads;
     const int p = (blockIdx.x / heads) % hw;
     const int b = blockIdx.x / (heads * hw);
     const int C = heads * HD, ld = 3 * C;
     const size_t fstride = (size_t)hw * ld;                       // distance between consecutive frames of one position
-    const bf16* base = qkv + ((size_t)b * T * hw + p) * ld + head * HD;
+    const T16* base = qkv + ((size_t)b * T * hw + p) * ld + head * HD;
 
     for (int idx = lane; idx < T * (HD / 4); idx += 64) {
         const int j = idx / (HD / 4), c = (idx - j * (HD / 4)) * 4;
-        *reinterpret_cast<bf16x4*>(&ks[j * HD + c]) = *reinterpret_cast<const bf16x4*>(base + j * fstride + C + c);
-        *reinterpret_cast<bf16x4*>(&vs[j * HD + c]) = *reinterpret_cast<const bf16x4*>(base + j * fstride + 2 * C + c);
+        *reinterpret_cast<v4_t*>(&ks[j * HD + c]) = *reinterpret_cast<const v4_t*>(base + j * fstride + C + c);
+        *reinterpret_cast<v4_t*>(&vs[j * HD + c]) = *reinterpret_cast<const v4_t*>(base + j * fstride + 2 * C + c);
     }
     float q[HH];
     {
-        const bf16* qrow = base + (size_t)min(t, T - 1) * fstride + half * HH;
+        const T16* qrow = base + (size_t)min(t, T - 1) * fstride + half * HH;
 #pragma unroll
         for (int i = 0; i < V4; ++i) {
-            const bf16x4 v = *reinterpret_cast<const bf16x4*>(qrow + 4 * i);
+            const v4_t v = *reinterpret_cast<const v4_t*>(qrow + 4 * i);
 #pragma unroll
             for (int k = 0; k < 4; ++k) q[4 * i + k] = (float)v[k] * scale_log2e;
         }
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const bf16* __restric
         if (j < T) {
 #pragma unroll
             for (int i = 0; i < V4; ++i) {
-                const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(&ks[j * HD + half * HH + 4 * i]);
+                const v4_t k4 = *reinterpret_cast<const v4_t*>(&ks[j * HD + half * HH + 4 * i]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc = fmaf(q[4 * i + k], (float)k4[k], acc);
             }
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const bf16* __restric
         if (j < T) {
 #pragma unroll
             for (int i = 0; i < V4; ++i) {
-                const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(&vs[j * HD + half * HH + 4 * i]);
+                const v4_t v4 = *reinterpret_cast<const v4_t*>(&vs[j * HD + half * HH + 4 * i]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[4 * i + k] = fmaf(s[j], (float)v4[k], o[4 * i + k]);
             }
@@ -83,12 +84,12 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const bf16* __restric
     }
     if (t < T) {
         const float inv = 1.f / l;
-        bf16* orow = out + (((size_t)b * T + t) * hw + p) * C + head * HD + half * HH;
+        T16* orow = out + (((size_t)b * T + t) * hw + p) * C + head * HD + half * HH;
 #pragma unroll
         for (int i = 0; i < V4; ++i) {
-            const bf16x4 v = {(bf16)(o[4 * i] * inv), (bf16)(o[4 * i + 1] * inv), (bf16)(o[4 * i + 2] * inv),
-                              (bf16)(o[4 * i + 3] * inv)};
-            *reinterpret_cast<bf16x4*>(orow + 4 * i) = v;
+            const v4_t v = {(T16)(o[4 * i] * inv), (T16)(o[4 * i + 1] * inv), (T16)(o[4 * i + 2] * inv),
+                            (T16)(o[4 * i + 3] * inv)};
+            *reinterpret_cast<v4_t*>(orow + 4 * i) = v;
         }
     }
 }
@@ -96,17 +97,23 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const bf16* __restric
 }  // namespace
 
 extern "C" int vda_temporal_attention(const void* qkv, void* out, int batch, int T, int hw, int heads, int hd, float scale,
-                                      void* stream) {
+                                      int dtype, void* stream) {
     if (!qkv || !out || batch <= 0 || T <= 0 || hw <= 0 || heads <= 0) return VDA_EINVAL;
     if (T > 32) return VDA_ESHAPE;
+    if (dtype != VDA_T_BF16 && dtype != VDA_T_F16) return VDA_EINVAL;
     const long blocks = (long)batch * hw * heads;
     if (blocks > 0x7fffffffL) return VDA_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bf16* qp = reinterpret_cast<const bf16*>(qkv);
-    bf16* op = reinterpret_cast<bf16*>(out);
     const float sl = scale * 1.4426950408889634f;
-#define TA_LAUNCH(H) \
-    hipLaunchKernelGGL(temporal_attn_kernel<H>, dim3((unsigned)blocks), dim3(64), 0, s, qp, op, T, hw, heads, sl)
+#define TA_LAUNCH(H)                                                                                                     \
+    do {                                                                                                                 \
+        if (dtype == VDA_T_F16)                                                                                          \
+            hipLaunchKernelGGL((temporal_attn_kernel<H, f16>), dim3((unsigned)blocks), dim3(64), 0, s,                    \
+                               reinterpret_cast<const f16*>(qkv), reinterpret_cast<f16*>(out), T, hw, heads, sl);        \
+        else                                                                                                             \
+            hipLaunchKernelGGL((temporal_attn_kernel<H, bf16>), dim3((unsigned)blocks), dim3(64), 0, s,                   \
+                               reinterpret_cast<const bf16*>(qkv), reinterpret_cast<bf16*>(out), T, hw, heads, sl);      \
+    } while (0)
     switch (hd) {
         case 8: TA_LAUNCH(8); break;
         case 16: TA_LAUNCH(16); break;

@@ -1,0 +1,174 @@
+"""The per-window forward pass as a sequence of libvda_hip kernel launches on the current HIP stream.
+
+Layouts in HBM (T frames, hp x wp patches, N = hp*wp + 1 tokens, D embed dim):
+  * encoder residual stream  fp32 [frame][token][D]; every GEMM operand bf16; accumulation fp32;
+  * head feature maps        bf16 channels-last [frame][y][x][C] (C padded to a multiple of 64), so a 1x1 convolution or
+                             Linear is a plain GEMM on the same buffer and the temporal modules need no transposes;
+  * temporal hidden state    fp32 [frame][position][C];
+  * depth                    fp32 [frame][H][W].
+torch is used for allocation (caching allocator = workspace reuse) and the stream only.
+"""
+import torch
+
+from . import hip
+from .spec import TEMPORAL_HEADS
+
+BF16 = torch.bfloat16
+
+
+def _empty(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+class Engine:
+    def __init__(self, packed):
+        self.w = packed
+        self.dev = packed.device
+        self.hdt = packed.head_dtype         # 16-bit storage/operand type of the DPT head and the temporal modules
+
+    # ---- small wrappers -------------------------------------------------------------------------------------------
+    def linear(self, a, w, out, bias=None, **kw):
+        M, K = a.shape[0], a.shape[-1]
+        N = w.shape[0]
+        hip.gemm(a, w, out, M=M, N=N, K=K, lda=a.stride(0), ldc=out.stride(0), bias=bias, **kw)
+        return out
+
+    def conv3(self, x, w, bias, cout, stride=1, **kw):
+        """x: bf16 [frames, h, w, cin] -> bf16 [frames, oh, ow, cout]."""
+        f, h, wd, cin = x.shape
+        oh, ow = (h - 1) // stride + 1, (wd - 1) // stride + 1
+        out = _empty((f, oh, ow, cout), self.hdt, self.dev)
+        hip.gemm(x, w, out, M=f * oh * ow, N=cout, K=9 * cin, lda=0, ldc=cout, bias=bias, conv=(h, wd, cin, oh, ow, stride), **kw)
+        return out
+
+    def resize(self, x, oh, ow):
+        f, h, wd, c = x.shape
+        if (h, wd) == (oh, ow):
+            return x
+        out = _empty((f, oh, ow, c), self.hdt, self.dev)
+        hip.bilinear_nhwc(x, out, f, h, wd, oh, ow, c)
+        return out
+
+    # ---- encoder (reference: dinov2.py:212-231, 271-281, 297-321; block.py:82-107) --------------------------------------
+    def encoder(self, x, frames, H, W):
+        w, dev = self.w, self.dev
+        D, heads = w.D, w.heads
+        hp, wp = H // 14, W // 14
+        hw, N = hp * wp, hp * wp + 1
+        M = frames * N
+        cols = _empty((frames * hw, 640), BF16, dev)
+        hip.im2col_patch14(x, cols, frames, H, W, 640)
+        tok = _empty((frames * hw, D), torch.float32, dev)
+        self.linear(cols, w.patch_w, tok, w.patch_b)
+        xs = _empty((M, D), torch.float32, dev)
+        hip.assemble_tokens(tok, w.cls, w.pos_table(hp, wp), xs, frames, hw, D)
+        del cols, tok
+        y = _empty((M, D), BF16, dev)
+        qkv = _empty((M, 3 * D), BF16, dev)
+        att = _empty((M, D), BF16, dev)
+        hid = _empty((M, 4 * D), BF16, dev)
+        taps = []
+        for i, b in enumerate(w.blocks):
+            hip.layernorm(xs, y, b["ln1_w"], b["ln1_b"], M, D, 1e-6)
+            self.linear(y, b["wqkv"], qkv, b["bqkv"])
+            hip.attention(qkv, att, frames, N, heads)
+            self.linear(att, b["wproj"], xs, b["bproj"], gamma=b["ls1"], resid=xs, ldr=D)
+            hip.layernorm(xs, y, b["ln2_w"], b["ln2_b"], M, D, 1e-6)
+            self.linear(y, b["wfc1"], hid, b["bfc1"], act=hip.ACT_GELU)
+            self.linear(hid, b["wfc2"], xs, b["bfc2"], gamma=b["ls2"], resid=xs, ldr=D)
+            if i in w.taps:
+                t = _empty((frames * hw, D), self.hdt, dev)
+                hip.layernorm(xs, t, w.norm_w, w.norm_b, frames * hw, D, 1e-6, rows_per_group=hw, in_group=N, in_skip=1)
+                taps.append(t)
+        return taps
+
+    # ---- temporal module (reference: motion_module.py:102-126, 164-177, 230-297) ----------------------------------------
+    def motion(self, idx, x, B, T):
+        m, dev = self.w.motion[idx], self.dev
+        f, h, wd, C = x.shape
+        hw = h * wd
+        M = f * hw
+        xf = x.reshape(M, C)
+        work = _empty((f * 32 * 2,), torch.float64, dev)
+        g = _empty((M, C), self.hdt, dev)
+        hip.groupnorm(xf, g, m["gn_w"], m["gn_b"], work, f, hw, C, 32, 1e-6)
+        hs = _empty((M, C), torch.float32, dev)
+        self.linear(g, m["in_w"], hs, m["in_b"])
+        n = g                                            # reuse as the normed-activation buffer
+        qkv = _empty((M, 3 * C), self.hdt, dev)
+        o = _empty((M, C), self.hdt, dev)
+        hd = C // TEMPORAL_HEADS
+        for a in m["attn"]:
+            hip.layernorm(hs, n, a["ln_w"], a["ln_b"], M, C, 1e-5, pe=a["pe"], pe_hw=hw, pe_T=T)
+            self.linear(n, a["wqkv"], qkv)
+            hip.temporal_attention(qkv, o, B, T, hw, TEMPORAL_HEADS, hd, hd ** -0.5)
+            self.linear(o, a["wo"], hs, a["bo"], resid=hs, ldr=C)
+        hip.layernorm(hs, n, m["ffn_w"], m["ffn_b"], M, C, 1e-5)
+        ff = _empty((M, 4 * C), self.hdt, dev)
+        self.linear(n, m["ff1_w"], ff, m["ff1_b"], epi=hip.EPI_GEGLU)
+        self.linear(ff, m["ff2_w"], o, m["ff2_b"], resid=hs, ldr=C)          # bf16 out: only proj_out reads it
+        out = _empty((f, h, wd, C), self.hdt, dev)
+        self.linear(o, m["out_w"], out.reshape(M, C), m["out_b"], resid=xf, ldr=C)
+        return out
+
+    # ---- RefineNet fusion (reference: util/blocks.py:68-91, 135-162) -----------------------------------------------------
+    def fusion(self, idx, x0, x1, oh, ow):
+        r, Fp = self.w.refine[idx], self.w.Fp
+        y = x0
+        if x1 is not None:
+            t = self.conv3(x1, r["u1c1_w"], r["u1c1_b"], Fp, relu_in=True, act=hip.ACT_RELU)
+            y = self.conv3(t, r["u1c2_w"], r["u1c2_b"], Fp, resid=x1.reshape(-1, Fp), ldr=Fp, resid2=x0.reshape(-1, Fp), ldr2=Fp)
+        t = self.conv3(y, r["u2c1_w"], r["u2c1_b"], Fp, relu_in=True, act=hip.ACT_RELU)
+        z = self.conv3(t, r["u2c2_w"], r["u2c2_b"], Fp, resid=y.reshape(-1, Fp), ldr=Fp)
+        # the 1x1 out_conv is applied BEFORE the bilinear resize: both are linear and the interpolation weights sum to
+        # one, so the result is the same function at a quarter of the multiply-adds of the reference order
+        f, h, wd, _ = z.shape
+        zc = _empty((f, h, wd, Fp), self.hdt, self.dev)
+        self.linear(z.reshape(-1, Fp), r["out_w"], zc.reshape(-1, Fp), r["out_b"])
+        return self.resize(zc, oh, ow)
+
+    # ---- DPT head (reference: dpt_temporal.py:53-114, dpt.py:60-124) ---------------------------------------------------
+    def head(self, taps, B, T, hp, wp):
+        w, dev = self.w, self.dev
+        frames = B * T
+        hw = hp * wp
+        proj = []
+        for i in range(4):
+            p = _empty((frames * hw, w.ocp[i]), self.hdt, dev)
+            self.linear(taps[i], w.proj_w[i], p, w.proj_b[i])
+            proj.append(p)
+        l1 = _empty((frames, 4 * hp, 4 * wp, w.ocp[0]), self.hdt, dev)
+        hip.gemm(proj[0], w.rs0_w, l1, M=frames * hw, N=16 * w.ocp[0], K=w.ocp[0], lda=w.ocp[0], ldc=w.ocp[0], bias=w.rs0_b,
+                 epi=hip.EPI_CONVT, convt=(hp, wp, 4, w.ocp[0]))
+        l2 = _empty((frames, 2 * hp, 2 * wp, w.ocp[1]), self.hdt, dev)
+        hip.gemm(proj[1], w.rs1_w, l2, M=frames * hw, N=4 * w.ocp[1], K=w.ocp[1], lda=w.ocp[1], ldc=w.ocp[1], bias=w.rs1_b,
+                 epi=hip.EPI_CONVT, convt=(hp, wp, 2, w.ocp[1]))
+        l3 = proj[2].reshape(frames, hp, wp, w.ocp[2])
+        l4 = self.conv3(proj[3].reshape(frames, hp, wp, w.ocp[3]), w.rs3_w, w.rs3_b, w.ocp[3], stride=2)
+        l3 = self.motion(0, l3, B, T)
+        l4 = self.motion(1, l4, B, T)
+        r1 = self.conv3(l1, w.rn_w[0], None, w.Fp)
+        r2 = self.conv3(l2, w.rn_w[1], None, w.Fp)
+        r3 = self.conv3(l3, w.rn_w[2], None, w.Fp)
+        r4 = self.conv3(l4, w.rn_w[3], None, w.Fp)
+        p4 = self.fusion(4, r4, None, hp, wp)
+        p4 = self.motion(2, p4, B, T)
+        p3 = self.fusion(3, p4, r3, 2 * hp, 2 * wp)
+        p3 = self.motion(3, p3, B, T)
+        p2 = self.fusion(2, p3, r2, 4 * hp, 4 * wp)
+        p1 = self.fusion(1, p2, r1, 8 * hp, 8 * wp)
+        o1 = self.conv3(p1, w.oc1_w, w.oc1_b, w.F2p)
+        o1 = self.resize(o1, 14 * hp, 14 * wp)
+        depth = _empty((frames, 14 * hp, 14 * wp), torch.float32, dev)
+        hip.gemm(o1, w.oc2_w, depth, M=frames * 196 * hw, N=32, K=9 * w.F2p, lda=0, ldc=4, bias=w.oc2_b, epi=hip.EPI_DOT,
+                 dot_w=w.dot_w, dot_b=w.dot_b, conv=(14 * hp, 14 * wp, w.F2p, 14 * hp, 14 * wp, 1))
+        return depth
+
+    def forward(self, x):
+        """x: fp32 [B, T, 3, H, W] on the device -> fp32 [B, T, H, W] (reference: video_depth.py:58-65).
+        The reference's trailing resize to (H, W) is the identity (the head already emits 14*hp x 14*wp = H x W with
+        align_corners=True) and its ReLU is idempotent after the head's own, so neither is launched."""
+        B, T, ch, H, W = x.shape
+        hp, wp = H // 14, W // 14
+        taps = self.encoder(x.reshape(B * T, ch, H, W), B * T, H, W)
+        return self.head(taps, B, T, hp, wp).reshape(B, T, H, W)

@@ -13,13 +13,13 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvda_hip.so")
 
 A_LINEAR, A_CONV3 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
-T_NONE, T_F32, T_BF16 = 0, 1, 2
+T_NONE, T_F32, T_BF16, T_F16 = 0, 1, 2, 3
 EPI_PLAIN, EPI_GEGLU, EPI_CONVT, EPI_DOT = 0, 1, 2, 3
 
 EXPORTS = [
     "vda_version", "vda_gemm", "vda_attention", "vda_layernorm", "vda_groupnorm", "vda_bilinear_nhwc", "vda_bilinear_f32",
     "vda_im2col_patch14", "vda_assemble_tokens", "vda_temporal_attention", "vda_scale_shift_sums", "vda_solve_scale_shift",
-    "vda_affine_blend",
+    "vda_affine_blend", "vda_preprocess_u8",
 ]
 
 
@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
         ("lda", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int), ("ldr2", C.c_int),
         ("a_mode", C.c_int), ("act", C.c_int), ("epi", C.c_int), ("out_type", C.c_int), ("resid_type", C.c_int),
-        ("relu_in", C.c_int),
+        ("ab_type", C.c_int), ("relu_in", C.c_int),
         ("in_h", C.c_int), ("in_w", C.c_int), ("cin", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int), ("stride", C.c_int),
         ("ct_h", C.c_int), ("ct_w", C.c_int), ("ct_k", C.c_int), ("ct_c", C.c_int),
     ]
@@ -50,19 +50,20 @@ def lib():
         l.vda_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
         l.vda_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.vda_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
-                                    C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+                                    C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.vda_groupnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                    C.c_int, C.c_float, C.c_void_p]
-        l.vda_bilinear_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
+                                    C.c_int, C.c_float, C.c_int, C.c_void_p]
+        l.vda_bilinear_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
         l.vda_bilinear_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         l.vda_im2col_patch14.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.vda_assemble_tokens.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]
         l.vda_temporal_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
-                                             C.c_void_p]
+                                             C.c_int, C.c_void_p]
         l.vda_scale_shift_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         l.vda_solve_scale_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         l.vda_affine_blend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_long,
                                        C.c_void_p]
+        l.vda_preprocess_u8.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
         for name in EXPORTS[1:]:
             getattr(l, name).restype = C.c_int
         _lib = l
@@ -80,6 +81,13 @@ def _ptr(t):
 def _check(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what} failed with code {rc}")
+
+
+_TYPES = {torch.float32: T_F32, torch.bfloat16: T_BF16, torch.float16: T_F16}
+
+
+def _type(t):
+    return _TYPES[t.dtype]
 
 
 def _dev(*ts):
@@ -113,8 +121,11 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
     g.dot_b = float(dot_b)
     g.M, g.N, g.K, g.lda, g.ldc, g.ldr, g.ldr2 = M, N, K, lda, ldc, ldr, ldr2
     g.act, g.epi, g.relu_in = act, epi, int(bool(relu_in))
-    g.out_type = T_F32 if out.dtype == torch.float32 else T_BF16
-    g.resid_type = T_NONE if resid is None else (T_F32 if resid.dtype == torch.float32 else T_BF16)
+    if a.dtype != w.dtype or (resid2 is not None and resid2.dtype != a.dtype):
+        raise TypeError("vda_gemm: a, w and resid2 must share one 16-bit type")
+    g.ab_type = _type(a)
+    g.out_type = _type(out)
+    g.resid_type = T_NONE if resid is None else _type(resid)
     if conv is not None:
         g.a_mode = A_CONV3
         g.in_h, g.in_w, g.cin, g.out_h, g.out_w, g.stride = conv
@@ -136,18 +147,19 @@ def layernorm(x, out, weight, bias, rows, Cdim, eps, rows_per_group=None, in_gro
     if rows_per_group is None:
         rows_per_group = in_group = rows
     _check(lib().vda_layernorm(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), rows, Cdim, eps, rows_per_group, in_group,
-                               in_skip, _ptr(pe), pe_hw, pe_T, _stream()), "vda_layernorm")
+                               in_skip, _ptr(pe), pe_hw, pe_T, _type(out), _stream()), "vda_layernorm")
 
 
 def groupnorm(x, out, weight, bias, work, frames, hw, Cdim, groups, eps):
     _dev(x, out, weight, bias, work)
     _check(lib().vda_groupnorm(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(work), frames, hw, Cdim, groups, eps,
-                               _stream()), "vda_groupnorm")
+                               _type(x), _stream()), "vda_groupnorm")
 
 
 def bilinear_nhwc(x, out, frames, in_h, in_w, out_h, out_w, Cdim):
     _dev(x, out)
-    _check(lib().vda_bilinear_nhwc(_ptr(x), _ptr(out), frames, in_h, in_w, out_h, out_w, Cdim, _stream()), "vda_bilinear_nhwc")
+    _check(lib().vda_bilinear_nhwc(_ptr(x), _ptr(out), frames, in_h, in_w, out_h, out_w, Cdim, _type(x), _stream()),
+           "vda_bilinear_nhwc")
 
 
 def bilinear_f32(x, out, frames, in_h, in_w, out_h, out_w, relu=False):
@@ -167,7 +179,8 @@ def assemble_tokens(tok, cls, pos, x, frames, hw, D):
 
 def temporal_attention(qkv, out, batch, T, hw, heads, hd, scale):
     _dev(qkv, out)
-    _check(lib().vda_temporal_attention(_ptr(qkv), _ptr(out), batch, T, hw, heads, hd, scale, _stream()), "vda_temporal_attention")
+    _check(lib().vda_temporal_attention(_ptr(qkv), _ptr(out), batch, T, hw, heads, hd, scale, _type(qkv), _stream()),
+           "vda_temporal_attention")
 
 
 def scale_shift_sums(pred, target, sums, n):
@@ -183,3 +196,8 @@ def solve_scale_shift(sums, ss):
 def affine_blend(x, pre, out, ss, w_pre, w_post, n):
     _dev(x, pre, out, ss)
     _check(lib().vda_affine_blend(_ptr(x), _ptr(pre), _ptr(out), _ptr(ss), w_pre, w_post, n, _stream()), "vda_affine_blend")
+
+
+def preprocess_u8(frames_u8, out, frames, h0, w0, H, W):
+    _dev(frames_u8, out)
+    _check(lib().vda_preprocess_u8(_ptr(frames_u8), _ptr(out), frames, h0, w0, H, W, _stream()), "vda_preprocess_u8")

@@ -1,0 +1,121 @@
+"""Drop-in ``VideoDepthAnything`` for MI355X: same constructor, ``state_dict`` keys, ``forward`` and
+``infer_video_depth`` as the reference class (reference: video_depth_anything/video_depth.py:35-209 and
+metric_depth/video_depth_anything/video_depth.py:67-270), computed by hand-written gfx950 kernels.
+
+There is no CPU or eager-PyTorch path: ``forward`` raises if the module or the input is not on a ROCm device or the
+kernel library is not built.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .engine import Engine
+from .packing import PackedWeights
+from .spec import ENCODERS, state_dict_spec
+from .windows import INFER_LEN, KEYFRAMES, OVERLAP, network_size, window_plan, Stitcher
+
+__all__ = ["VideoDepthAnything", "INFER_LEN", "OVERLAP", "KEYFRAMES"]
+
+
+def _install(root, dotted, tensor, buffer):
+    """Register ``tensor`` under the dotted name, creating plain container modules on the way."""
+    parts = dotted.split(".")
+    mod = root
+    for name in parts[:-1]:
+        nxt = getattr(mod, name, None) if name in mod._modules else None
+        if nxt is None:
+            nxt = nn.Module()
+            mod.add_module(name, nxt)
+        mod = nxt
+    if buffer:
+        mod.register_buffer(parts[-1], tensor, persistent=True)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class VideoDepthAnything(nn.Module):
+    def __init__(self, encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024], use_bn=False, use_clstoken=False,
+                 num_frames=32, pe="ape"):
+        super().__init__()
+        if encoder not in ENCODERS:
+            raise ValueError(f"encoder {encoder!r} is not supported (vits, vitl)")
+        if use_bn or use_clstoken or pe != "ape":
+            raise NotImplementedError("only use_bn=False, use_clstoken=False, pe='ape' (the published checkpoints) are built")
+        assert num_frames > 0
+        self.encoder = encoder
+        self.features = features
+        self.out_channels = list(out_channels)
+        self.num_frames = num_frames
+        self.intermediate_layer_idx = {"vits": [2, 5, 8, 11], "vitl": [4, 11, 17, 23]}
+        # The reference clamps input_size to 420 when device == 'cuda' (video_depth.py:75-78), which on ROCm would
+        # make 518-pixel inference impossible; its CPU path and the metric copy do not clamp.  Off unless asked for.
+        self.clamp_input_size_on_gpu = False
+        # 16-bit operand type of the DPT head and temporal modules (the encoder is always bf16).  fp16 has the same MFMA
+        # rate as bf16 and 3 more mantissa bits; with bf16 here the depth error is 1.6e-2 max-relative (above the 1e-2
+        # bound), with fp16 it is set by the bf16 encoder alone.  The reference's own GPU default is fp16 autocast.
+        self.head_dtype = torch.float16
+        gen = torch.Generator().manual_seed(0)
+        for key, (shape, kind) in state_dict_spec(encoder, features, self.out_channels, num_frames).items():
+            if kind in ("nw",):
+                t = torch.ones(shape)
+            elif kind in ("b", "nb", "b_out0", "b_out2"):
+                t = torch.zeros(shape)
+            elif kind == "ls":
+                t = torch.ones(shape)
+            elif kind == "pe":
+                from .spec import sinusoid_table
+                t = torch.from_numpy(sinusoid_table(shape[1], shape[2]))
+            else:
+                t = torch.empty(shape).normal_(0.0, 0.02, generator=gen)
+            _install(self, key, t, buffer=(kind == "pe"))
+        self._packed = None
+        self._packed_key = None
+        self._engine = None
+
+    # ---- weights -> kernel layouts, rebuilt whenever the parameters change or move -----------------------------------
+    def _weights_key(self):
+        p = self.pretrained.cls_token
+        return (p.device, self.head_dtype, tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values()))
+
+    def _ensure_engine(self):
+        dev = self.pretrained.cls_token.device
+        if dev.type != "cuda":
+            raise RuntimeError("VideoDepthAnything (MI355X build) has no CPU path: call .to('cuda') on a ROCm device first")
+        hip.lib()
+        key = self._weights_key()
+        if self._engine is None or key != self._packed_key:
+            self._packed = PackedWeights(self.state_dict(), self.encoder, self.features, self.out_channels, dev, self.head_dtype)
+            self._engine = Engine(self._packed)
+            self._packed_key = key
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, x):
+        """``x[B, T, 3, H, W]`` (ImageNet-normalised RGB, H and W multiples of 14, T <= num_frames) -> ``[B, T, H, W]`` fp32."""
+        if x.dim() != 5 or x.shape[2] != 3:
+            raise ValueError(f"expected input [B, T, 3, H, W], got {tuple(x.shape)}")
+        B, T, _, H, W = x.shape
+        assert H % 14 == 0, f"Input image height {H} is not a multiple of patch height 14"
+        assert W % 14 == 0, f"Input image width {W} is not a multiple of patch width: 14"
+        if T > self.num_frames:
+            raise ValueError(f"T={T} exceeds the temporal position table ({self.num_frames} frames)")
+        if not x.is_cuda:
+            raise RuntimeError("forward() needs a device tensor: the MI355X build has no CPU path")
+        eng = self._ensure_engine()
+        with torch.cuda.device(x.device):
+            return eng.forward(x.float().contiguous())
+
+    @torch.no_grad()
+    def infer_video_depth(self, frames, target_fps, input_size=518, device="cuda", fp32=False, batch_size=16,
+                          use_cpu_offload=False):
+        """Depth for every frame of a video (reference: video_depth.py:67-209).
+
+        ``frames``: uint8 RGB ``[N, H0, W0, 3]`` array or a list of ``[H0, W0, 3]`` frames.  Returns
+        ``(float32 [N, H0, W0], target_fps)``.  Windows of ``min(32, batch_size)`` frames with key-frame carry-over;
+        with ``batch_size >= 32`` consecutive windows are affinely aligned and cross-faded, otherwise they are
+        concatenated unaligned exactly like the reference does.  ``fp32`` and ``use_cpu_offload`` are accepted for
+        signature compatibility: arithmetic is always bf16 MFMA with fp32 accumulation, and weights stay in HBM.
+        """
+        from .pipeline import run_video
+        return run_video(self, frames, target_fps, input_size=input_size, device=device, batch_size=batch_size)

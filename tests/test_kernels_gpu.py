@@ -18,6 +18,9 @@ DEV = "cuda"
 BF = torch.bfloat16
 
 
+HALVES = [torch.bfloat16, torch.float16]
+
+
 def rnd(shape, seed, scale=1.0, dtype=BF):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
@@ -67,9 +70,10 @@ def test_gemm_epilogue_bias_gelu_gamma_residual(M, N, K):
     close(out, F.relu(acc) + r16.float() + r2.float(), BF_OUT, "relu + 2 residuals")
 
 
-def test_gemm_geglu():
+@pytest.mark.parametrize("dt", HALVES)
+def test_gemm_geglu(dt):
     M, C = 700, 192
-    a, w = rnd((M, C), 1), rnd((8 * C, C), 2, 1 / math.sqrt(C))
+    a, w = rnd((M, C), 1, 1.0, dt), rnd((8 * C, C), 2, 1 / math.sqrt(C), dt)
     bias = rnd((8 * C,), 3, 0.1, torch.float32)
     proj = a.float() @ w.float().t() + bias
     val, gate = proj.chunk(2, dim=-1)
@@ -79,7 +83,7 @@ def test_gemm_geglu():
     wv, wg = w[:n].reshape(n // 16, 16, C), w[n:].reshape(n // 16, 16, C)
     wi = torch.stack([wv, wg], 1).reshape(8 * C, C).contiguous()
     bi = torch.stack([bias[:n].reshape(n // 16, 16), bias[n:].reshape(n // 16, 16)], 1).reshape(-1).contiguous()
-    out = torch.empty((M, n), dtype=BF, device=DEV)
+    out = torch.empty((M, n), dtype=dt, device=DEV)
     hip.gemm(a, wi, out, M=M, N=8 * C, K=C, lda=C, ldc=n, bias=bi, epi=hip.EPI_GEGLU)
     close(out, want, BF_OUT, "geglu")
 
@@ -98,18 +102,19 @@ def test_gemm_conv_transpose(k, C):
     close(out, want, BF_OUT, "convT")
 
 
+@pytest.mark.parametrize("dt", HALVES)
 @pytest.mark.parametrize("stride,cin,cout,relu_in", [(1, 64, 64, True), (1, 128, 256, False), (2, 192, 192, False), (1, 64, 32, False)])
-def test_gemm_conv3x3(stride, cin, cout, relu_in):
+def test_gemm_conv3x3(stride, cin, cout, relu_in, dt):
     B, h, w_ = 2, 19, 13
-    x = rnd((B, cin, h, w_), 1)
-    wt = rnd((cout, cin, 3, 3), 2, 1 / math.sqrt(9 * cin))
+    x = rnd((B, cin, h, w_), 1, 1.0, dt)
+    wt = rnd((cout, cin, 3, 3), 2, 1 / math.sqrt(9 * cin), dt)
     bias = rnd((cout,), 3, 0.1, torch.float32)
     xin = F.relu(x.float()) if relu_in else x.float()
     want = F.conv2d(xin, wt.float(), bias, stride=stride, padding=1).permute(0, 2, 3, 1)
     oh, ow = want.shape[1], want.shape[2]
     a = x.permute(0, 2, 3, 1).contiguous()
     wg = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
-    out = torch.full((B, oh, ow, cout), float("nan"), dtype=BF, device=DEV)
+    out = torch.full((B, oh, ow, cout), float("nan"), dtype=dt, device=DEV)
     hip.gemm(a, wg, out, M=B * oh * ow, N=cout, K=9 * cin, lda=0, ldc=cout, bias=bias, relu_in=relu_in,
              conv=(h, w_, cin, oh, ow, stride))
     close(out, want, BF_OUT, "conv3x3")
@@ -157,9 +162,10 @@ def test_attention_sharp_softmax_rescale():
 def test_layernorm(rows, C):
     x = rnd((rows, C), 1, 2.0, torch.float32) + 0.5
     w, b = rnd((C,), 2, 1.0, torch.float32), rnd((C,), 3, 1.0, torch.float32)
-    out = torch.empty((rows, C), dtype=BF, device=DEV)
-    hip.layernorm(x, out, w, b, rows, C, 1e-6)
-    close(out, F.layer_norm(x, (C,), w, b, 1e-6), BF_OUT, "layernorm")
+    for dt, tol in ((BF, BF_OUT), (torch.float16, 1e-3)):
+        out = torch.empty((rows, C), dtype=dt, device=DEV)
+        hip.layernorm(x, out, w, b, rows, C, 1e-6)
+        close(out, F.layer_norm(x, (C,), w, b, 1e-6), tol, "layernorm")
 
 
 def test_layernorm_drop_class_token_and_position_table():
@@ -178,9 +184,10 @@ def test_layernorm_drop_class_token_and_position_table():
     close(out, want.reshape(B * T, hw, C), BF_OUT, "layernorm + pe")
 
 
+@pytest.mark.parametrize("dt", HALVES)
 @pytest.mark.parametrize("frames,hw,C", [(4, 37 * 37, 256), (3, 100, 192), (2, 361, 384), (2, 50, 64)])
-def test_groupnorm(frames, hw, C):
-    x = rnd((frames, hw, C), 1, 1.5) + 0.3
+def test_groupnorm(frames, hw, C, dt):
+    x = rnd((frames, hw, C), 1, 1.5, dt) + 0.3
     w, b = rnd((C,), 2, 1.0, torch.float32), rnd((C,), 3, 1.0, torch.float32)
     out = torch.empty_like(x)
     work = torch.empty(frames * 32 * 2, dtype=torch.float64, device=DEV)
@@ -189,11 +196,12 @@ def test_groupnorm(frames, hw, C):
     close(out, want, BF_OUT, "groupnorm")
 
 
+@pytest.mark.parametrize("dt", HALVES)
 @pytest.mark.parametrize("ih,iw,oh,ow", [(19, 19, 37, 37), (37, 66, 74, 132), (5, 7, 10, 14), (8, 8, 14, 14), (6, 6, 6, 6)])
-def test_bilinear(ih, iw, oh, ow):
+def test_bilinear(ih, iw, oh, ow, dt):
     frames, C = 2, 64
-    x = rnd((frames, ih, iw, C), 1)
-    out = torch.empty((frames, oh, ow, C), dtype=BF, device=DEV)
+    x = rnd((frames, ih, iw, C), 1, 1.0, dt)
+    out = torch.empty((frames, oh, ow, C), dtype=dt, device=DEV)
     hip.bilinear_nhwc(x, out, frames, ih, iw, oh, ow, C)
     want = F.interpolate(x.float().permute(0, 3, 1, 2), size=(oh, ow), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
     close(out, want, BF_OUT, "bilinear nhwc")
@@ -228,11 +236,12 @@ def test_patch_embed_front_end():
     assert torch.equal(xt, want)
 
 
+@pytest.mark.parametrize("dt", HALVES)
 @pytest.mark.parametrize("B,T,hw,heads,hd", [(1, 32, 12, 8, 24), (2, 5, 7, 8, 48), (1, 32, 9, 8, 8), (1, 32, 10, 8, 128), (1, 4, 6, 8, 32), (1, 1, 5, 8, 8)])
-def test_temporal_attention(B, T, hw, heads, hd):
+def test_temporal_attention(B, T, hw, heads, hd, dt):
     C = heads * hd
-    qkv = rnd((B * T * hw, 3 * C), 1)
-    out = torch.full((B * T * hw, C), float("nan"), dtype=BF, device=DEV)
+    qkv = rnd((B * T * hw, 3 * C), 1, 1.0, dt)
+    out = torch.full((B * T * hw, C), float("nan"), dtype=dt, device=DEV)
     hip.temporal_attention(qkv, out, B, T, hw, heads, hd, hd ** -0.5)
     q, k, v = qkv.float().reshape(B, T, hw, 3, heads, hd).permute(3, 0, 2, 4, 1, 5)      # [B, hw, heads, T, hd]
     want = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v

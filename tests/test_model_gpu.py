@@ -1,0 +1,83 @@
+"""End-to-end parity of the HIP forward pass and whole-video inference against the reference's golden outputs and the
+CPU oracle.  Tolerances are the stated ones: max relative depth error <= 1e-2 (floored at 1e-3 of the map's maximum,
+because the depth is ReLU-clamped) and |AbsRel| <= 0.5 %."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import vda_oracle as O  # noqa: E402
+from video_depth_anything import spec  # noqa: E402
+from video_depth_anything.video_depth import VideoDepthAnything  # noqa: E402
+
+MAX_REL = 1e-2
+ABS_REL = 5e-3
+
+
+def synth_frames(n, h, w, seed):
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = np.empty((n, h, w, 3), np.uint8)
+    for i in range(n):
+        r = (xx * 255.0 / max(w - 1, 1) + 3 * i) % 256
+        g = (yy * 255.0 / max(h - 1, 1) + 5 * i) % 256
+        b = 255 - r
+        f = np.stack([r, g, b], -1) + rs.randint(-20, 21, (h, w, 3))
+        out[i] = np.clip(f, 0, 255).astype(np.uint8)
+    return out
+
+
+@pytest.fixture(scope="module")
+def vits():
+    sd = {k: torch.from_numpy(v) for k, v in spec.synth_state_dict(**spec.MODEL_CONFIGS["vits"], seed=1).items()}
+    m = VideoDepthAnything(**spec.MODEL_CONFIGS["vits"])
+    m.load_state_dict(sd, strict=True)
+    return m.to("cuda").eval(), sd
+
+
+def report(name, got, want):
+    mr, ar = O.max_rel_err(got, want), O.abs_rel(got, want)
+    print(f"{name}: max_rel={mr:.3e} abs_rel={ar:.3e}")
+    return mr, ar
+
+
+@pytest.mark.parametrize("name,shape,seed", [("T32", (1, 32, 3, 70, 98), 41), ("T4", (1, 4, 3, 70, 98), 42),
+                                             ("B2T3", (2, 3, 3, 56, 42), 43), ("T32_sq", (1, 32, 3, 42, 42), 44)])
+def test_forward_matches_reference_goldens(golden_dir, vits, name, shape, seed):
+    model, _ = vits
+    g = np.load(os.path.join(golden_dir, "g4_forward.npz"))
+    x = torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32)).cuda()
+    out = model(x)
+    assert out.shape == g[name].shape and out.dtype == torch.float32
+    mr, ar = report(name, out.cpu().numpy(), g[name])
+    assert mr <= MAX_REL and ar <= ABS_REL
+
+
+@pytest.mark.parametrize("n,bs", [(1, 32), (31, 32), (33, 32), (33, 16), (60, 32), (60, 16), (77, 32)])
+def test_whole_video_matches_reference_goldens(golden_dir, vits, n, bs):
+    model, _ = vits
+    g = np.load(os.path.join(golden_dir, "g5_video.npz"))
+    frames = synth_frames(n, 28, 42, 500 + n)
+    out, fps = model.infer_video_depth(frames, 24, input_size=28, device="cuda", fp32=True, batch_size=bs)
+    assert fps == 24 and out.shape == (n, 28, 42) and out.dtype == np.float32
+    mr, ar = report(f"video N{n} bs{bs}", out, g[f"N{n}_bs{bs}"])
+    assert mr <= MAX_REL and ar <= ABS_REL
+
+
+def test_forward_mid_size_against_oracle(vits):
+    """A larger, non-square input (resampled positional table, 10 x 14 patches) against the oracle run on the CPU."""
+    model, sd = vits
+    x = torch.from_numpy(np.random.RandomState(7).standard_normal((1, 8, 3, 140, 196)).astype(np.float32))
+    want = O.forward(sd, x, "vits").numpy()
+    got = model(x.cuda()).cpu().numpy()
+    mr, ar = report("mid", got, want)
+    assert mr <= MAX_REL and ar <= ABS_REL
+
+
+def test_no_cpu_path(vits):
+    model, _ = vits
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 2, 3, 28, 28))
