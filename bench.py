@@ -1,0 +1,148 @@
+"""Throughput of the per-window forward pass (the metric of BASELINE.json) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step is one 32-frame window of VDA-Large at 518x518 through ``VideoDepthAnything.forward`` with the input already in
+HBM.  Windows depend only on input frames, so with N > 1 every rank runs its own windows (weak scaling, no data-path
+collective); the reported value is all ranks' frames divided by the slowest rank's time.
+
+The JSON line also carries
+  roofline     : the dominant kernel (the 128x128 bf16 MFMA GEMM of the encoder linears) timed per launch with HIP events on
+                 its own stream inside the timed region: algorithmic FLOP per launch / average launch time vs the dense bf16 peak;
+  cpu_baseline : the CPU oracle (fp32 torch restatement of the reference) timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "monocular-depth-estimation_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0
+# reference model under FlopCounterMode, GFLOP per model-frame (2*MAC), T = 32
+GFLOP_PER_FRAME = {("vitl", 518, 518): 1404.67, ("vits", 518, 518): 121.28, ("vitl", 518, 924): 2761.52,
+                   ("vits", 518, 924): 264.43, ("vitl", 1036, 1036): 7822.31, ("vits", 1036, 1036): 898.78}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--encoder", default="vitl", choices=["vits", "vitl"])
+    ap.add_argument("--height", type=int, default=518)
+    ap.add_argument("--width", type=int, default=518)
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    from video_depth_anything import hip, spec
+    from video_depth_anything.video_depth import VideoDepthAnything
+
+    cfg = spec.MODEL_CONFIGS[args.encoder]
+    model = VideoDepthAnything(**cfg)             # random-init weights of the named architecture (no checkpoints offline)
+    model = model.to(dev).eval()
+    T, H, W = args.frames, args.height, args.width
+    x = torch.from_numpy(np.random.RandomState(rank).standard_normal((1, T, 3, H, W)).astype(np.float32)).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model(x)
+    barrier()
+    timing = None
+    if not args.no_kernel_timing and rank == 0:
+        timing = hip.enable_gemm_timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model(x)
+    barrier()
+    dt = time.perf_counter() - t0
+    if timing is not None:
+        hip.disable_gemm_timing()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        fps = world * args.steps * T / dt
+        out = {
+            "metric": "frames/sec at 518px (VDA-L, 32-frame windows)" if (args.encoder, H, W, T) == ("vitl", 518, 518, 32)
+            else f"frames/sec ({args.encoder}, {T}-frame windows at {H}x{W})",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Video-Depth-Anything-{'Large (ViT-L)' if args.encoder == 'vitl' else 'Small (ViT-S)'} "
+                                   f"forward, 1x{T}x3x{H}x{W} window resident in HBM, random-init weights",
+                       "windows_per_step_per_gpu": 1, "parallelism": f"window-parallel x{world}",
+                       "operands": "encoder bf16 MFMA, head fp16 MFMA, fp32 accumulate"},
+        }
+        gf = GFLOP_PER_FRAME.get((args.encoder, H, W))
+        if gf:
+            out["model_tflops"] = round(fps / world * gf / 1e3, 2)
+            out["model_mfma_frac"] = round(fps / world * gf / 1e3 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)
+        if timing is not None:
+            launches, flops, ms = timing.summary()
+            if launches:
+                ach = flops / (ms * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                                   "kernel": "gemm_kernel<128,128,2,2,LINEAR,bf16> (encoder qkv/proj/fc1/fc2)",
+                                   "launches": launches, "avg_launch_us": round(1e3 * ms / launches, 2),
+                                   "avg_gflop_per_launch": round(flops / launches / 1e9, 3)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.encoder, H, W)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(encoder, H, W):
+    """The CPU oracle on a bounded sample: a 4-frame window (per-frame cost of the encoder and head does not depend on the
+    window length; only the negligible temporal attention does)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vda_oracle as O
+    from video_depth_anything import spec
+    cfg = spec.MODEL_CONFIGS[encoder]
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    sd = {}
+    shapes = spec.state_dict_spec(**cfg)
+    g = torch.Generator().manual_seed(0)
+    for k, (shape, kind) in shapes.items():       # throughput does not depend on the values: cheap random fill
+        sd[k] = torch.randn(shape, generator=g) * 0.02
+    frames = 2 if encoder == "vitl" else 8
+    x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, frames, 3, H, W)).astype(np.float32))
+    t0 = time.perf_counter()
+    O.forward(sd, x, encoder)
+    dt = time.perf_counter() - t0
+    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"CPU oracle (fp32 torch restatement), one {frames}-frame window at {H}x{W}, single run, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

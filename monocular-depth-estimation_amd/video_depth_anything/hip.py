@@ -134,7 +134,42 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
         g.a_mode = A_LINEAR
     if convt is not None:
         g.ct_h, g.ct_w, g.ct_k, g.ct_c = convt
+    t = _gemm_timing
+    if t is not None and conv is None and g.ab_type == T_BF16 and N > 64 and epi == EPI_PLAIN:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(lib().vda_gemm(C.byref(g), _stream()), "vda_gemm")
+        e1.record()
+        t.events.append((e0, e1, 2.0 * M * N * K))
+        return
     _check(lib().vda_gemm(C.byref(g), _stream()), "vda_gemm")
+
+
+class GemmTiming:
+    """Per-launch HIP-event timing of the 128x128-tile bf16 linear GEMM (the kernel that dominates the forward pass).
+    The events are recorded on the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.events = []
+
+    def summary(self):
+        """(launches, total algorithmic FLOP, total milliseconds); call after a device synchronize."""
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.events)
+        return len(self.events), sum(f for _, _, f in self.events), ms
+
+
+_gemm_timing = None
+
+
+def enable_gemm_timing():
+    global _gemm_timing
+    _gemm_timing = GemmTiming()
+    return _gemm_timing
+
+
+def disable_gemm_timing():
+    global _gemm_timing
+    _gemm_timing = None
 
 
 def attention(qkv, out, frames, n_tok, heads):
