@@ -81,3 +81,24 @@ def test_no_cpu_path(vits):
     model, _ = vits
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 2, 3, 28, 28))
+
+
+def test_vitl_full_window_518_against_oracle_on_device():
+    """The flagship configuration (ViT-L, 1x32x3x518x518).  The oracle restatement is executed by torch in fp32 on the
+    GPU here (same code as the CPU oracle; the CPU run takes minutes at this size)."""
+    cfg = spec.MODEL_CONFIGS["vitl"]
+    sd = {k: torch.from_numpy(v) for k, v in spec.synth_state_dict(**cfg, seed=1).items()}
+    m = VideoDepthAnything(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda").eval()
+    x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 32, 3, 518, 518)).astype(np.float32)).cuda()
+    got = m(x).cpu().numpy()
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    sd_dev = {k: v.cuda() for k, v in sd.items()}
+    want = O.forward(sd_dev, x, "vitl").cpu().numpy()
+    assert got.shape == want.shape == (1, 32, 518, 518)
+    worst = max(O.max_rel_err(got[0, t], want[0, t]) for t in range(32))
+    ar = O.abs_rel(got, want)
+    print(f"vitl 518 full window: worst per-frame max_rel={worst:.3e} abs_rel={ar:.3e} depth range {want.min():.3f}..{want.max():.3f}")
+    assert worst <= MAX_REL and ar <= ABS_REL
