@@ -178,8 +178,7 @@ def fusion_block(sd, idx, x0, x1=None, size=None):
 
 def head_forward(sd, taps, hp, wp, T):
     """Temporal DPT head (reference: dpt_temporal.py:53-114, dpt.py:60-124).  ``taps``: 4 x [B*T, hp*wp, D].
-    Returns ``[B*T, 1, 14hp, 14wp]``.  The reference's 4-frame micro-batching of the last stages is a memory
-    device only (every op there is per-sample), so it is not restated."""
+    Returns ``[B*T, 1, 14hp, 14wp]``."""
     h = "head."
     x0 = taps[0]
     layers = []
@@ -205,13 +204,20 @@ def head_forward(sd, taps, hp, wp, T):
     p4 = temporal_module(sd, 2, p4, T)
     p3 = fusion_block(sd, 3, p4, r3, size=r2.shape[2:])
     p3 = temporal_module(sd, 3, p3, T)
-    p2 = fusion_block(sd, 2, p3, r2, size=r1.shape[2:])
-    p1 = fusion_block(sd, 1, p2, r1, size=None)
-    o = F.conv2d(p1, _t(sd, sc + "output_conv1.weight", x0), _t(sd, sc + "output_conv1.bias", x0), padding=1)
-    o = F.interpolate(o, (14 * hp, 14 * wp), mode="bilinear", align_corners=True)
-    o = F.relu(F.conv2d(o, _t(sd, sc + "output_conv2.0.weight", x0), _t(sd, sc + "output_conv2.0.bias", x0), padding=1))
-    o = F.relu(F.conv2d(o, _t(sd, sc + "output_conv2.2.weight", x0), _t(sd, sc + "output_conv2.2.bias", x0)))
-    return o
+    # the two finest stages run in micro-batches of 4 frames exactly when the reference does (dpt_temporal.py:88-114);
+    # every op there is per-sample, so this only bounds the size of the largest intermediate tensor
+    n = p3.shape[0]
+    mb = n if (n <= 4 or n % 4 != 0) else 4
+    outs = []
+    for i in range(0, n, mb):
+        p2 = fusion_block(sd, 2, p3[i:i + mb], r2[i:i + mb], size=r1.shape[2:])
+        p1 = fusion_block(sd, 1, p2, r1[i:i + mb], size=None)
+        o = F.conv2d(p1, _t(sd, sc + "output_conv1.weight", x0), _t(sd, sc + "output_conv1.bias", x0), padding=1)
+        o = F.interpolate(o, (14 * hp, 14 * wp), mode="bilinear", align_corners=True)
+        o = F.relu(F.conv2d(o, _t(sd, sc + "output_conv2.0.weight", x0), _t(sd, sc + "output_conv2.0.bias", x0), padding=1))
+        o = F.relu(F.conv2d(o, _t(sd, sc + "output_conv2.2.weight", x0), _t(sd, sc + "output_conv2.2.bias", x0)))
+        outs.append(o)
+    return torch.cat(outs, dim=0)
 
 
 @torch.no_grad()

@@ -29,7 +29,13 @@ with torch.no_grad():
     print(f"full          : max_rel {O.max_rel_err(got, want):.3e} abs_rel {O.abs_rel(got, want):.3e}")
     enc_only = fin(O.head_forward(sd, [t.float().reshape(r.shape) for t, r in zip(my_taps, ref_taps)], hp, wp, T))
     print(f"encoder only  : max_rel {O.max_rel_err(enc_only, want):.3e} abs_rel {O.abs_rel(enc_only, want):.3e}")
-    head_only = eng.head([t.to(torch.bfloat16).reshape(-1, t.shape[-1]).contiguous() for t in ref_taps], 1, T, hp, wp).cpu().numpy()
+    head_only = eng.head([t.to(eng.hdt).reshape(-1, t.shape[-1]).contiguous() for t in ref_taps], 1, T, hp, wp).reshape(T, H, W).cpu().numpy()
     print(f"head only     : max_rel {O.max_rel_err(head_only, want):.3e} abs_rel {O.abs_rel(head_only, want):.3e}")
     r16 = fin(O.head_forward(sd, [t.bfloat16().float() for t in ref_taps], hp, wp, T))
     print(f"taps rounded  : max_rel {O.max_rel_err(r16, want):.3e} abs_rel {O.abs_rel(r16, want):.3e}")
+    e = np.abs(head_only - want) / np.maximum(np.abs(want), 1e-3 * np.abs(want).max())
+    idx = np.argwhere(e > 0.02)
+    print("bad pixels:", len(idx), "of", e.size)
+    if len(idx):
+        print("frames:", np.unique(idx[:, 0])[:40]); print("rows:", np.unique(idx[:, 1])[:60]); print("cols:", np.unique(idx[:, 2])[:60])
+        for f, y, x_ in idx[:10]: print(f, y, x_, head_only[f, y, x_], want[f, y, x_])
