@@ -1,0 +1,239 @@
+// 256x256-tile GEMM / implicit-GEMM convolution for large problems: 8 waves (2 along M x 4 along N), each wave owns a
+// 128x64 output block = 8x4 mfma_f32_16x16x32 tiles (128 accumulator registers); K step 64; 128 KiB of LDS.
+//
+// Software pipeline.  A K-tile (256 rows of A, 256 rows of W, 64 deep) is split into four 16 KiB REGIONS by WHEN the
+// waves need them, not by where they sit in the tile:
+//     A0s = for every wave the first 64 of its 128 A rows      B0s = for every wave the first 32 of its 64 W rows
+//     A1s = the other 64 A rows                                B1s = the other 32 W rows
+// and a K-tile is multiplied in four phases of 16 MFMAs per wave (one quadrant of the wave's block each):
+//     P1: read A0s,B0s -> quadrant (0,0)    P2: read B1s -> (0,1)    P3: read A1s -> (1,1)    P4: (B0s kept) -> (1,0)
+// Every phase also issues the global_load_lds copies of ONE region of a later K-tile (2 instructions per lane):
+//     P1(t): B1s(t+1)    P2(t): A1s(t+1)    P3(t): A0s(t+2)    P4(t): B0s(t+2)
+// followed by a COUNTED wait `s_waitcnt vmcnt(8)` (the four most recent regions stay in flight) and a raw s_barrier; a second
+// barrier follows the MFMAs.  A phase is thus two barrier intervals, [reads + copy issue + wait] and [16 MFMAs], and the
+// waves 4-7 (the SIMD partners of waves 0-3) run ONE interval behind waves 0-3, so that on each SIMD the matrix pipe of
+// one wave overlaps the LDS reads of the other.
+// Invariants (two LDS buffers, K-tile t lives in buffer t & 1):
+//   * a region is re-filled no earlier than two phases after its last read: A0s,B0s are last read in P1 and refilled in
+//     P3/P4 of the same tile; B1s last read in P2, refilled in P1 of the next tile; A1s last read in P3, refilled in P2
+//     of the next tile.  Reads of phase r have returned before that wave's MFMAs of phase r, hence before it arrives at
+//     the barrier of phase r+1, which the refilling wave has passed;
+//   * a region is read no earlier than the phase after the wait that retired it: with one region issued per phase,
+//     vmcnt(8) at phase p retires everything issued up to phase p-4, and every region is issued at least 5 phases
+//     before the phase that reads it.  Each lane waits for its own copies, the barrier extends that to all lanes: the
+//     late half finishes its phase-p wait in the interval just before the early half's phase-(p+1) reads;
+//   * both hold for the staggered halves because all distances above are counted in whole phases (two intervals) and the
+//     stagger is one interval.
+// In the last two K-tiles, phases that have nothing left to issue wait with vmcnt(0) instead.
+#include "gemm_common.h"
+
+namespace vda {
+
+namespace {
+
+constexpr int REGION = 16384;
+// region slots inside a buffer, in issue order
+constexpr int R_A0 = 0, R_B0 = 1, R_B1 = 2, R_A1 = 3;
+
+__device__ __forceinline__ void wait_vm8() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void phase_barrier() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int AMODE, bool RELU_IN, typename T>
+__global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const GemmTiles gt) {
+    typedef typename Vec<T>::v8 frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    int tm, tn;
+    tile_of_workgroup(gt, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // ---- staging roles: a region is 128 rows x 8 chunks of 16 bytes = 1024 pieces, two per lane ---------------------------
+    const int srow = tid >> 3;                               // 0..63
+    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);        // source chunk of this lane's (lane-linear) LDS slot
+    const bf16* a_src[2][2];                                 // [region a][piece i]
+    int a_iy[2][2], a_ix[2][2];
+    const bf16* w_src[2][2];                                 // [region b][piece i]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // region-local row i*64 + srow belongs to the waves with wm == i: tile row i*128 + a*64 + srow
+            const int m = min(m0 + i * 128 + a * 64 + srow, p.M - 1);
+            if (AMODE == VDA_A_LINEAR) {
+                a_src[a][i] = reinterpret_cast<const bf16*>(p.a) + (size_t)m * p.lda + schunk * 8;
+            } else {
+                const int hw = p.out_h * p.out_w;
+                const int img = m / hw, rem = m - img * hw;
+                const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+                a_iy[a][i] = oy * p.stride - 1;
+                a_ix[a][i] = ox * p.stride - 1;
+                a_src[a][i] = reinterpret_cast<const bf16*>(p.a) + (size_t)img * p.in_h * p.in_w * p.cin + schunk * 8;
+            }
+        }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // region-local row i*64 + srow = wn*32 + r with wn = 2i + (srow >> 5), r = srow & 31: tile row wn*64 + b*32 + r
+            const int n = min(n0 + (2 * i + (srow >> 5)) * 64 + b * 32 + (srow & 31), p.N - 1);
+            w_src[b][i] = reinterpret_cast<const bf16*>(p.w) + (size_t)n * p.K + schunk * 8;
+        }
+    const bf16* zsrc = reinterpret_cast<const bf16*>(p.zeros) + schunk * 8;
+    const int cpt = (AMODE == VDA_A_CONV3) ? p.cin / BK : 1;
+
+    auto issue_a = [&](int a, int kt, int buf) {
+        char* dst = smem + buf * (4 * REGION) + (a == 0 ? R_A0 : R_A1) * REGION;
+        if (AMODE == VDA_A_LINEAR) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) glds16(a_src[a][i] + kt * BK, dst + (i * 512 + wave * 64) * 16);
+        } else {
+            const int tap = kt / cpt, cc = kt - tap * cpt;
+            const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int iy = a_iy[a][i] + dy, ix = a_ix[a][i] + dx;
+                const bool ok = (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
+                const bf16* s = ok ? a_src[a][i] + ((size_t)iy * p.in_w + ix) * p.cin + cc * BK : zsrc;
+                glds16(s, dst + (i * 512 + wave * 64) * 16);
+            }
+        }
+    };
+    auto issue_b = [&](int b, int kt, int buf) {
+        char* dst = smem + buf * (4 * REGION) + (b == 0 ? R_B0 : R_B1) * REGION;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(w_src[b][i] + kt * BK, dst + (i * 512 + wave * 64) * 16);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    const int frow = lane & 15, fq = lane >> 4;
+    // fragment read offsets inside a region (the same for both k-steps up to the chunk index)
+    int a_off[4][2], b_off[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_off[i][ks] = tile_off(wm * 64 + i * 16 + frow, ks * 4 + fq);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b_off[j][ks] = tile_off(wn * 32 + j * 16 + frow, ks * 4 + fq);
+    }
+
+    frag_t af[4][2], bf0[2][2], bf1[2][2];
+    auto read_a = [&](const char* region) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                af[i][ks] = *reinterpret_cast<const frag_t*>(region + a_off[i][ks]);
+                if (RELU_IN) af[i][ks] = relu8(af[i][ks]);
+            }
+    };
+    auto read_b = [&](const char* region, frag_t (&bf)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bf[j][ks] = *reinterpret_cast<const frag_t*>(region + b_off[j][ks]);
+    };
+    auto quadrant = [&](int a, int b, frag_t (&bf)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a * 4 + i][b * 2 + j] = mfma16(bf[j][ks], af[i][ks], acc[a * 4 + i][b * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // The two waves that share a SIMD are waves w and w + 4, i.e. the two values of wm.  The wm == 1 half runs one barrier
+    // interval behind the other half, so that on every SIMD one wave is in its MFMA interval while its partner is in its
+    // LDS-read / copy-issue interval.  group1 is wave-uniform by construction (readfirstlane makes that provable).
+    const bool group1 = __builtin_amdgcn_readfirstlane(wave) >= 4;
+
+    // ---- prologue: all of K-tile 0, and the first two regions of K-tile 1 ---------------------------------------------------
+    issue_a(0, 0, 0);
+    issue_b(0, 0, 0);
+    issue_b(1, 0, 0);
+    issue_a(1, 0, 0);
+    if (nk > 1) {
+        issue_a(0, 1, 1);
+        issue_b(0, 1, 1);
+        wait_vm8();
+    } else {
+        wait_vm0();
+    }
+    phase_barrier();
+    if (group1) phase_barrier();
+
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const char* buf = smem + cur * (4 * REGION);
+        const bool next1 = t + 1 < nk, next2 = t + 2 < nk;
+        // P1
+        read_a(buf + R_A0 * REGION);
+        read_b(buf + R_B0 * REGION, bf0);
+        if (next1) { issue_b(1, t + 1, cur ^ 1); wait_vm8(); } else { wait_vm0(); }
+        phase_barrier();
+        quadrant(0, 0, bf0);
+        phase_barrier();
+        // P2
+        read_b(buf + R_B1 * REGION, bf1);
+        if (next1) { issue_a(1, t + 1, cur ^ 1); wait_vm8(); } else { wait_vm0(); }
+        phase_barrier();
+        quadrant(0, 1, bf1);
+        phase_barrier();
+        // P3
+        read_a(buf + R_A1 * REGION);
+        if (next2) { issue_a(0, t + 2, cur); wait_vm8(); } else { wait_vm0(); }
+        phase_barrier();
+        quadrant(1, 1, bf1);
+        phase_barrier();
+        // P4
+        if (next2) { issue_b(0, t + 2, cur); wait_vm8(); } else { wait_vm0(); }
+        phase_barrier();
+        quadrant(1, 0, bf0);
+        phase_barrier();
+    }
+    if (!group1) phase_barrier();     // every wave executes the same number of barriers
+
+    gemm_epilogue<8, 4>(p, acc, m0 + wm * 128 + frow, n0 + wn * 64 + fq * 4, fq, smem + wave * STAGE_BYTES);
+}
+
+template <typename T>
+int launch_t(const VdaGemmArgs& a, hipStream_t s) {
+    GemmTiles gt{(a.M + 255) / 256, (a.N + 255) / 256};
+    const int lds = 8 * REGION;
+    dim3 grid(gt.tiles_m * gt.tiles_n);
+#define VDA_LAUNCH256(MODE, RELU)                                                                                    \
+    do {                                                                                                             \
+        auto k = gemm256_kernel<MODE, RELU, T>;                                                                      \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
+        hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a, gt);                                                       \
+    } while (0)
+    if (a.a_mode == VDA_A_CONV3) {
+        if (a.relu_in) VDA_LAUNCH256(VDA_A_CONV3, true); else VDA_LAUNCH256(VDA_A_CONV3, false);
+    } else {
+        if (a.relu_in) VDA_LAUNCH256(VDA_A_LINEAR, true); else VDA_LAUNCH256(VDA_A_LINEAR, false);
+    }
+#undef VDA_LAUNCH256
+    return hip_rc(hipGetLastError());
+}
+
+}  // namespace
+
+int launch_gemm256(const VdaGemmArgs& a, hipStream_t s) {
+    return a.ab_type == VDA_T_F16 ? launch_t<f16>(a, s) : launch_t<bf16>(a, s);
+}
+
+}  // namespace vda

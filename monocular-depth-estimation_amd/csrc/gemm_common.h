@@ -1,0 +1,256 @@
+// Pieces shared by the GEMM kernels: operand-type dispatch of the MFMA, typed vector loads/stores, the workgroup -> tile
+// map and the fused epilogue (see vda_gemm in include/vda_hip.h).
+#pragma once
+#include "common.h"
+
+namespace vda {
+
+constexpr int BK = 64;   // K step of every GEMM kernel (one LDS row = 64 16-bit values = 128 bytes)
+
+struct GemmTiles {
+    int tiles_m, tiles_n;
+};
+
+typedef short short8 __attribute__((ext_vector_type(8)));
+
+template <typename V8>
+__device__ __forceinline__ V8 relu8(V8 v) {
+    // the float sign bit is the int16 sign bit, so max(int16, 0) is ReLU for bf16 and fp16 (and maps -0.0 to +0.0)
+    short8 s = __builtin_bit_cast(short8, v);
+    short8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    s = __builtin_elementwise_max(s, z);
+    return __builtin_bit_cast(V8, s);
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ f32x4 load4(const void* p, int type, size_t idx) {
+    if (type == VDA_T_F32) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + idx);
+    if (type == VDA_T_BF16) {
+        const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p) + idx);
+        return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+    }
+    const f16x4 r = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(p) + idx);
+    return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+}
+
+__device__ __forceinline__ void store4(void* out, int out_type, size_t idx, f32x4 v) {
+    if (out_type == VDA_T_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + idx) = v;
+    } else if (out_type == VDA_T_BF16) {
+        bf16x4 b = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(out) + idx) = b;
+    } else {
+        f16x4 b = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(out) + idx) = b;
+    }
+}
+
+// Workgroup -> output tile.  Workgroups b and b + 8 share an XCD, so workgroup ids are first remapped so that each XCD
+// gets a contiguous run of tiles (bijective for any grid size), then tiles are walked in bands of 8 row-tiles x all
+// column-tiles so that the tiles resident together in one XCD share A and W panels in its L2.
+__device__ __forceinline__ void tile_of_workgroup(const GemmTiles& gt, int& tm, int& tn) {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    constexpr int GM = 8;
+    const int per_band = GM * gt.tiles_n;
+    const int band = tile / per_band;
+    const int first = band * GM;
+    const int rows = min(GM, gt.tiles_m - first);
+    const int in_band = tile - band * per_band;
+    tm = first + in_band % rows;
+    tn = in_band / rows;
+}
+
+// Fused epilogue.  acc[i][j] is the 16x16 MFMA tile (i along M, j along N) of a wave, computed as mfma(W, A), so this
+// lane holds row  m = mrow0 + 16 i  and the 4 consecutive columns  n = ncol0 + 16 j + {0,1,2,3}, where
+// mrow0 = (wave's first row) + (lane & 15) and ncol0 = (wave's first column) + 4 (lane >> 4).
+//
+// `stage` is a wave-private LDS area of at least STAGE_BYTES (all main-loop LDS traffic of the workgroup must have
+// finished).  For plain and GEGLU epilogues whose output rows are 16-byte aligned the 16x(16 TN) block of one m-tile is
+// first written to `stage` in the output type and then copied out with 16 bytes per lane, so every global store
+// instruction writes whole, contiguous row segments (complete 128-byte lines for 64-column bf16 / 32-column fp32 blocks)
+// instead of 8-byte pieces scattered over 16 rows.
+constexpr int STAGE_BYTES = 16 * (4 * 16 * 4 + 16);     // 16 rows x (up to 64 fp32 columns + 16 bytes of padding)
+
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq,
+                                                     char* stage) {
+    const int lane = threadIdx.x & 63, frow = lane & 15;
+    const int esz = p.out_type == VDA_T_F32 ? 4 : 2;
+    const bool geglu = p.epi == VDA_EPI_GEGLU;
+    const int cols = geglu ? TN * 8 : TN * 16;               // output columns of the wave's block
+    const int row_bytes = cols * esz;
+    const int rs = row_bytes + 16;                            // padded LDS row stride
+    const int cpr = row_bytes >> 4;                           // 16-byte chunks per row
+    const int rpi = 64 / cpr;                                 // rows per copy-out instruction
+    const int wave_n0 = ncol0 - fq * 4;
+    const int out_n0 = geglu ? wave_n0 / 2 : wave_n0;        // first output column of the block
+    const int n_out = geglu ? p.N / 2 : p.N;
+    f32x4 bias[TN], gam[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = ncol0 + j * 16;
+        bias[j] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        gam[j] = (p.gamma && n < p.N) ? *reinterpret_cast<const f32x4*>(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    const int c_row = lane / cpr, c_chunk = lane - c_row * cpr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = mrow0 + i * 16;                          // this lane's row of the m-tile
+        char* srow = stage + frow * rs;
+        if (geglu) {
+#pragma unroll
+            for (int j = 0; j < TN; j += 2) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (acc[i][j][r] + bias[j][r]) * gelu_erf(acc[i][j + 1][r] + bias[j + 1][r]);
+                store4(srow, p.out_type, (j / 2) * 16 + fq * 4, v);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = ncol0 + j * 16;
+                f32x4 v = acc[i][j] + bias[j];
+                if (p.act == VDA_ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                } else if (p.act == VDA_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                v *= gam[j];
+                if (m < p.M && n < p.N) {
+                    if (p.resid_type != VDA_T_NONE) v += load4(p.resid, p.resid_type, (size_t)m * p.ldr + n);
+                    if (p.resid2) v += load4(p.resid2, p.ab_type, (size_t)m * p.ldr2 + n);
+                }
+                store4(srow, p.out_type, j * 16 + fq * 4, v);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's LDS writes are done before any of its lanes reads
+        const int mbase = mrow0 - frow + i * 16;                // first row of the m-tile
+        for (int r0 = 0; r0 < 16; r0 += rpi) {
+            const int row = r0 + c_row;
+            if (row < 16) {
+                const int mm = mbase + row;
+                const int col = (c_chunk << 4) / esz;          // first output column of this lane's chunk
+                const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * rs + (c_chunk << 4));
+                if (mm < p.M && out_n0 + col < n_out)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.out) + ((size_t)mm * p.ldc + out_n0 + col) * esz) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads returned before the next m-tile overwrites the area
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq,
+                                              char* stage = nullptr) {
+    if (stage && (p.epi == VDA_EPI_PLAIN || p.epi == VDA_EPI_GEGLU)) {
+        const int esz = p.out_type == VDA_T_F32 ? 4 : 2;
+        const int n_out = p.epi == VDA_EPI_GEGLU ? p.N / 2 : p.N;
+        const int cols = p.epi == VDA_EPI_GEGLU ? TN * 8 : TN * 16;
+        // 16-byte row alignment of the output, whole chunks inside N, and at most 64 chunks per 16-row block row set
+        if ((p.ldc * esz) % 16 == 0 && (n_out * esz) % 16 == 0 && (cols * esz) % 16 == 0 && (cols * esz) <= 256 &&
+            ((uintptr_t)p.out & 15) == 0) {
+            gemm_epilogue_staged<TM, TN>(p, acc, mrow0, ncol0, fq, stage);
+            return;
+        }
+    }
+    if (p.epi == VDA_EPI_DOT) {
+        float part[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) part[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = ncol0 + j * 16;
+            if (n < p.N) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+                const f32x4 dw = *reinterpret_cast<const f32x4*>(p.dot_w + n);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[i] += fmaxf(acc[i][j][r] + b[r], 0.f) * dw[r];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float v = part[i];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int m = mrow0 + i * 16;
+            if (fq == 0 && m < p.M) reinterpret_cast<float*>(p.out)[m] = fmaxf(v + p.dot_b, 0.f);
+        }
+        return;
+    }
+
+    if (p.epi == VDA_EPI_GEGLU) {
+        const int half0 = (ncol0 - fq * 4) / 2 + fq * 4;
+#pragma unroll
+        for (int j = 0; j < TN; j += 2) {
+            const int nv = ncol0 + j * 16;            // value columns; gate columns are 16 further
+            if (nv + 16 >= p.N) continue;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + nv);
+            const f32x4 bg = *reinterpret_cast<const f32x4*>(p.bias + nv + 16);
+            const int oc = half0 + (j / 2) * 16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow0 + i * 16;
+                if (m >= p.M) continue;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (acc[i][j][r] + bv[r]) * gelu_erf(acc[i][j + 1][r] + bg[r]);
+                store4(p.out, p.out_type, (size_t)m * p.ldc + oc, v);
+            }
+        }
+        return;
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = ncol0 + j * 16;
+        if (n >= p.N) continue;
+        int bias_n = n;
+        size_t col_off = n;
+        if (p.epi == VDA_EPI_CONVT) {
+            const int tap = n / p.ct_c, co = n - tap * p.ct_c;
+            const int ky = tap / p.ct_k, kx = tap - ky * p.ct_k;
+            bias_n = co;
+            col_off = ((size_t)ky * (p.ct_w * p.ct_k) + kx) * p.ldc + co;
+        }
+        f32x4 b = {0.f, 0.f, 0.f, 0.f}, g = {1.f, 1.f, 1.f, 1.f};
+        if (p.bias) b = *reinterpret_cast<const f32x4*>(p.bias + bias_n);
+        if (p.gamma) g = *reinterpret_cast<const f32x4*>(p.gamma + n);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = mrow0 + i * 16;
+            if (m >= p.M) continue;
+            f32x4 v = acc[i][j] + b;
+            if (p.act == VDA_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            } else if (p.act == VDA_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            v *= g;
+            if (p.resid_type != VDA_T_NONE) v += load4(p.resid, p.resid_type, (size_t)m * p.ldr + n);
+            if (p.resid2) v += load4(p.resid2, p.ab_type, (size_t)m * p.ldr2 + n);
+            size_t idx;
+            if (p.epi == VDA_EPI_CONVT) {
+                const int iy = m / p.ct_w, x = m - iy * p.ct_w;     // iy = img * ct_h + y
+                idx = ((size_t)iy * p.ct_k * (p.ct_w * p.ct_k) + (size_t)x * p.ct_k) * p.ldc + col_off;
+            } else {
+                idx = (size_t)m * p.ldc + col_off;
+            }
+            store4(p.out, p.out_type, idx, v);
+        }
+    }
+}
+
+// 256x256-tile kernel with the 4-phase software pipeline (gemm256.hip)
+int launch_gemm256(const VdaGemmArgs& a, hipStream_t s);
+
+}  // namespace vda

@@ -32,11 +32,12 @@ class GemmArgs(C.Structure):
         ("a_mode", C.c_int), ("act", C.c_int), ("epi", C.c_int), ("out_type", C.c_int), ("resid_type", C.c_int),
         ("ab_type", C.c_int), ("relu_in", C.c_int),
         ("in_h", C.c_int), ("in_w", C.c_int), ("cin", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int), ("stride", C.c_int),
-        ("ct_h", C.c_int), ("ct_w", C.c_int), ("ct_k", C.c_int), ("ct_c", C.c_int),
+        ("ct_h", C.c_int), ("ct_w", C.c_int), ("ct_k", C.c_int), ("ct_c", C.c_int), ("tile_cfg", C.c_int),
     ]
 
 
 _lib = None
+TILE_CFG = int(os.environ.get("VDA_GEMM_TILE_CFG", "0"))      # 0 = library default; see VdaGemmArgs.tile_cfg
 
 
 def lib():
@@ -108,7 +109,7 @@ def zero_page(device):
 
 
 def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr=0, resid2=None, ldr2=0, act=ACT_NONE,
-         epi=EPI_PLAIN, relu_in=False, conv=None, convt=None, dot_w=None, dot_b=0.0):
+         epi=EPI_PLAIN, relu_in=False, conv=None, convt=None, dot_w=None, dot_b=0.0, tile_cfg=None):
     """Enqueue one vda_gemm.  ``conv`` = (in_h, in_w, cin, out_h, out_w, stride); ``convt`` = (h, w, k, c)."""
     _dev(a, w, out, bias, gamma, resid, resid2, dot_w)
     g = GemmArgs()
@@ -121,6 +122,7 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
     g.dot_b = float(dot_b)
     g.M, g.N, g.K, g.lda, g.ldc, g.ldr, g.ldr2 = M, N, K, lda, ldc, ldr, ldr2
     g.act, g.epi, g.relu_in = act, epi, int(bool(relu_in))
+    g.tile_cfg = TILE_CFG if tile_cfg is None else tile_cfg
     if a.dtype != w.dtype or (resid2 is not None and resid2.dtype != a.dtype):
         raise TypeError("vda_gemm: a, w and resid2 must share one 16-bit type")
     g.ab_type = _type(a)
