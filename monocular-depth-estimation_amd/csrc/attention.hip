@@ -17,7 +17,12 @@ constexpr float LOG2E = 1.4426950408889634f;
 // swapped on rows 2,3 (mod 4) so the 4 rows of a transposed 4x16 block read fall on distinct banks
 __device__ __forceinline__ int v_off(int row, int col) { return row * 128 + ((col * 2) ^ (((row >> 1) & 1) << 6)); }
 
-__global__ __launch_bounds__(256) void attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int n_tok, int heads) {
+// Growth of the running maximum (natural-log units) below which the accumulated output is NOT rescaled: probabilities of a
+// tile may then reach e^DEFER instead of 1, harmless for bf16 operands with fp32 accumulation, and the 64-register
+// rescale pass is skipped on almost every tile once the maximum has settled.
+constexpr float DEFER = 4.0f;
+
+__global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int n_tok, int heads) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -104,23 +109,28 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16* __restrict__ qkv,
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-        const float mneg = -m_new * LOG2E;
-        m_run = m_new;
-        float psum = 0.f;
+        // Everything accumulated so far (o, l_run) is at scale exp(-m_run).  Move to a new maximum only if some query of
+        // the wave needs it (wave-uniform branch); all of the previous tile's P V products are already in o.
+        if (__builtin_amdgcn_ballot_w64(mx - m_run > DEFER) != 0) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        }
+        const float mneg = -m_run * LOG2E;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
         bf16x8 pf[2][2];
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float pv = __builtin_amdgcn_exp2f(fmaf(s[kbk][i], LOG2E, mneg));
-                psum += pv;
+                ps[i & 3] += pv;
                 pf[kbk][i >> 3][i & 7] = (bf16)pv;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 
 #pragma unroll
         for (int db = 0; db < 2; ++db)
