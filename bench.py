@@ -122,8 +122,8 @@ def main():
 
 
 def cpu_baseline(encoder, H, W):
-    """The CPU oracle on a bounded sample: a 4-frame window (per-frame cost of the encoder and head does not depend on the
-    window length; only the negligible temporal attention does)."""
+    """The CPU oracle on a bounded sample: one short window (per-frame cost of the encoder and head does not depend on the
+    window length; only the negligible temporal attention does), sized for roughly 15-25 s on 16 host threads."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vda_oracle as O
     from video_depth_anything import spec
@@ -135,7 +135,7 @@ def cpu_baseline(encoder, H, W):
     g = torch.Generator().manual_seed(0)
     for k, (shape, kind) in shapes.items():       # throughput does not depend on the values: cheap random fill
         sd[k] = torch.randn(shape, generator=g) * 0.02
-    frames = 2 if encoder == "vitl" else 8
+    frames = 12 if encoder == "vitl" else 32
     x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, frames, 3, H, W)).astype(np.float32))
     t0 = time.perf_counter()
     O.forward(sd, x, encoder)

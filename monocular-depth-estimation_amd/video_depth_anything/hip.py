@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvda_hip.so")
+# VDA_HIP_LIB selects another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("VDA_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libvda_hip.so")
 
 A_LINEAR, A_CONV3 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
