@@ -8,7 +8,7 @@ HBM.  Windows depend only on input frames, so with N > 1 every rank runs its own
 collective); the reported value is all ranks' frames divided by the slowest rank's time.
 
 The JSON line also carries
-  roofline     : the dominant kernel (the 128x128 bf16 MFMA GEMM of the encoder linears) timed per launch with HIP events on
+  roofline     : the dominant kernel (the 256x256-tile bf16 MFMA GEMM of the encoder linears) timed per launch with HIP events on
                  its own stream inside the timed region: algorithmic FLOP per launch / average launch time vs the dense bf16 peak;
   cpu_baseline : the CPU oracle (fp32 torch restatement of the reference) timed on the host cores on a bounded sample.
 """
@@ -110,7 +110,7 @@ def main():
                 ach = flops / (ms * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
-                                   "kernel": "gemm_kernel<128,128,2,2,LINEAR,bf16> (encoder qkv/proj/fc1/fc2)",
+                                   "kernel": "gemm256_kernel<LINEAR,bf16> (encoder qkv/proj/fc1/fc2)",
                                    "launches": launches, "avg_launch_us": round(1e3 * ms / launches, 2),
                                    "avg_gflop_per_launch": round(flops / launches / 1e9, 3)}
         if not args.no_cpu_baseline:

@@ -188,11 +188,12 @@ extern "C" int vda_gemm(const VdaGemmArgs* args, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (a.N <= 32) return launch<128, 32, 4, 1>(a, s);
     if (a.N <= 64) return launch<128, 64, 2, 2>(a, s);
-    // The 256x256 pipelined kernel runs one workgroup per CU, so nothing overlaps a tile's prologue and its output stores:
-    // it wins once the K loop is long enough to amortise them (measured: K = 4096 1121 vs 892 TFLOP/s, K = 1024 761 vs
-    // 878) and the grid still fills the chip with the larger tiles.
+    // The 256x256 pipelined kernel moves half as many bytes global -> LDS per MFMA as the 128x128 one, which is what bounds
+    // the latter (about 30 B/clk/CU of copy throughput on either); but it runs one workgroup per CU, so nothing overlaps a
+    // tile's prologue and its output stores.  It wins once the K loop amortises those and the grid still fills the chip
+    // (measured at M = 43840: K = 4096 1208 vs 870 TFLOP/s, K = 1024 835-953 vs 770-821; whole model +6.7 %).
     const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    const bool big = a.tile_cfg == 2 || (a.tile_cfg == 0 && a.N >= 192 && a.K >= 2048 && tiles256 >= 192);
+    const bool big = a.tile_cfg == 2 || (a.tile_cfg == 0 && a.N >= 192 && a.K >= 1024 && tiles256 >= 192);
     if (big) return launch_gemm256(a, s);
     return launch<128, 128, 2, 2>(a, s);
 }

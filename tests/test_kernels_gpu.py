@@ -19,6 +19,8 @@ BF = torch.bfloat16
 
 
 HALVES = [torch.bfloat16, torch.float16]
+# workgroup tiles of vda_gemm: library's choice, forced 128x128, forced 256x256 pipelined (small shapes exercise its M/N tails)
+TILE_CFGS = [0, 1, 2]
 
 
 def rnd(shape, seed, scale=1.0, dtype=BF):
@@ -41,37 +43,40 @@ def test_library_loads_and_reports_version():
     assert b"gfx950" in hip.lib().vda_version()
 
 
+@pytest.mark.parametrize("cfg", TILE_CFGS)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1370 * 2, 1152, 384), (77, 48 * 4, 1536), (513, 64, 64), (200, 32, 192)])
-def test_gemm_plain_exact_integers(M, N, K):
+def test_gemm_plain_exact_integers(M, N, K, cfg):
     """Small-integer operands make every product and sum exact: catches any fragment/layout mix-up bit for bit."""
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randint(-3, 4, (M, K), generator=g).to(BF).to(DEV)
     w = torch.randint(-3, 4, (N, K), generator=g).to(BF).to(DEV)
     out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
-    hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N)
+    hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N, tile_cfg=cfg)
     want = a.float() @ w.float().t()
     assert torch.equal(out, want)
 
 
+@pytest.mark.parametrize("cfg", TILE_CFGS)
 @pytest.mark.parametrize("M,N,K", [(1370, 1024, 1024), (999, 384, 1536)])
-def test_gemm_epilogue_bias_gelu_gamma_residual(M, N, K):
+def test_gemm_epilogue_bias_gelu_gamma_residual(M, N, K, cfg):
     a, w = rnd((M, K), 1), rnd((N, K), 2, 1 / math.sqrt(K))
     bias, gamma = rnd((N,), 3, 0.1, torch.float32), rnd((N,), 4, 1.0, torch.float32)
     resid = rnd((M, N), 5, 1.0, torch.float32)
     acc = a.float() @ w.float().t() + bias
     out = torch.empty((M, N), dtype=BF, device=DEV)
-    hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, act=hip.ACT_GELU)
+    hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, act=hip.ACT_GELU, tile_cfg=cfg)
     close(out, F.gelu(acc), BF_OUT, "gelu")
     x = resid.clone()
-    hip.gemm(a, w, x, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, gamma=gamma, resid=x, ldr=N)     # in place on the residual
+    hip.gemm(a, w, x, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, gamma=gamma, resid=x, ldr=N, tile_cfg=cfg)     # in place on the residual
     close(x, resid + gamma * acc, F32_OUT, "layerscale residual")
     r16, r2 = rnd((M, N), 6), rnd((M, N), 7)
-    hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, act=hip.ACT_RELU, resid=r16, ldr=N, resid2=r2, ldr2=N)
+    hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, act=hip.ACT_RELU, resid=r16, ldr=N, resid2=r2, ldr2=N, tile_cfg=cfg)
     close(out, F.relu(acc) + r16.float() + r2.float(), BF_OUT, "relu + 2 residuals")
 
 
+@pytest.mark.parametrize("cfg", TILE_CFGS)
 @pytest.mark.parametrize("dt", HALVES)
-def test_gemm_geglu(dt):
+def test_gemm_geglu(dt, cfg):
     M, C = 700, 192
     a, w = rnd((M, C), 1, 1.0, dt), rnd((8 * C, C), 2, 1 / math.sqrt(C), dt)
     bias = rnd((8 * C,), 3, 0.1, torch.float32)
@@ -84,12 +89,13 @@ def test_gemm_geglu(dt):
     wi = torch.stack([wv, wg], 1).reshape(8 * C, C).contiguous()
     bi = torch.stack([bias[:n].reshape(n // 16, 16), bias[n:].reshape(n // 16, 16)], 1).reshape(-1).contiguous()
     out = torch.empty((M, n), dtype=dt, device=DEV)
-    hip.gemm(a, wi, out, M=M, N=8 * C, K=C, lda=C, ldc=n, bias=bi, epi=hip.EPI_GEGLU)
+    hip.gemm(a, wi, out, M=M, N=8 * C, K=C, lda=C, ldc=n, bias=bi, epi=hip.EPI_GEGLU, tile_cfg=cfg)
     close(out, want, BF_OUT, "geglu")
 
 
+@pytest.mark.parametrize("cfg", TILE_CFGS)
 @pytest.mark.parametrize("k,C", [(4, 64), (2, 128)])
-def test_gemm_conv_transpose(k, C):
+def test_gemm_conv_transpose(k, C, cfg):
     B, h, w_ = 3, 5, 7
     x = rnd((B, C, h, w_), 1)
     wt = rnd((C, C, k, k), 2, 1 / math.sqrt(C))          # [Cin, Cout, k, k]
@@ -98,13 +104,14 @@ def test_gemm_conv_transpose(k, C):
     a = x.permute(0, 2, 3, 1).reshape(B * h * w_, C).contiguous()
     wg = wt.permute(2, 3, 1, 0).reshape(k * k * C, C).contiguous()       # n = (ky*k+kx)*C + co, k-dim = ci
     out = torch.full((B, h * k, w_ * k, C), float("nan"), dtype=BF, device=DEV)
-    hip.gemm(a, wg, out, M=B * h * w_, N=k * k * C, K=C, lda=C, ldc=C, bias=bias, epi=hip.EPI_CONVT, convt=(h, w_, k, C))
+    hip.gemm(a, wg, out, M=B * h * w_, N=k * k * C, K=C, lda=C, ldc=C, bias=bias, epi=hip.EPI_CONVT, convt=(h, w_, k, C), tile_cfg=cfg)
     close(out, want, BF_OUT, "convT")
 
 
 @pytest.mark.parametrize("dt", HALVES)
 @pytest.mark.parametrize("stride,cin,cout,relu_in", [(1, 64, 64, True), (1, 128, 256, False), (2, 192, 192, False), (1, 64, 32, False)])
-def test_gemm_conv3x3(stride, cin, cout, relu_in, dt):
+@pytest.mark.parametrize("cfg", TILE_CFGS)
+def test_gemm_conv3x3(stride, cin, cout, relu_in, dt, cfg):
     B, h, w_ = 2, 19, 13
     x = rnd((B, cin, h, w_), 1, 1.0, dt)
     wt = rnd((cout, cin, 3, 3), 2, 1 / math.sqrt(9 * cin), dt)
@@ -116,7 +123,7 @@ def test_gemm_conv3x3(stride, cin, cout, relu_in, dt):
     wg = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
     out = torch.full((B, oh, ow, cout), float("nan"), dtype=dt, device=DEV)
     hip.gemm(a, wg, out, M=B * oh * ow, N=cout, K=9 * cin, lda=0, ldc=cout, bias=bias, relu_in=relu_in,
-             conv=(h, w_, cin, oh, ow, stride))
+             conv=(h, w_, cin, oh, ow, stride), tile_cfg=cfg)
     close(out, want, BF_OUT, "conv3x3")
 
 
