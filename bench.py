@@ -10,6 +10,7 @@ collective); the reported value is all ranks' frames divided by the slowest rank
 The JSON line also carries
   roofline     : the dominant kernel (the 256x256-tile bf16 MFMA GEMM of the encoder linears) timed per launch with HIP events on
                  its own stream inside the timed region: algorithmic FLOP per launch / average launch time vs the dense bf16 peak;
+  end_to_end   : the whole-video path (`infer_video_depth`) from host frames to host depth, PCIe included (N = 1 only);
   cpu_baseline : the CPU oracle (fp32 torch restatement of the reference) timed on the host cores on a bounded sample.
 """
 import argparse
@@ -42,6 +43,7 @@ def main():
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,12 +115,32 @@ def main():
                                    "kernel": "gemm256_kernel<LINEAR,bf16> (encoder qkv/proj/fc1/fc2)",
                                    "launches": launches, "avg_launch_us": round(1e3 * ms / launches, 2),
                                    "avg_gflop_per_launch": round(flops / launches / 1e9, 3)}
+        if not args.no_end_to_end and world == 1:
+            out["end_to_end"] = end_to_end(model, H, W)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.encoder, H, W)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def end_to_end(model, H, W, n=98):
+    """``infer_video_depth`` on a synthetic uint8 video held in host memory (frames already at network size): upload,
+    device preprocessing, all windows, alignment, cross-fade and the copy of every depth map back to the host.  Not part
+    of `value`: it is the PCIe-inclusive rate of the whole video path, in VIDEO frames (a window advances 22 frames)."""
+    frames = np.random.RandomState(1).randint(0, 256, (n, H, W, 3), dtype=np.uint8)
+    model.infer_video_depth(frames[:33], 30, input_size=min(H, W), device="cuda", batch_size=32)      # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    depth, _ = model.infer_video_depth(frames, 30, input_size=min(H, W), device="cuda", batch_size=32)
+    dt = time.perf_counter() - t0
+    assert depth.shape == (n, H, W)
+    from video_depth_anything.windows import window_plan
+    windows = len(window_plan(n, 32)[0])
+    return {"video_frames_per_s": round(n / dt, 2), "model_frames_per_s": round(32 * windows / dt, 2), "frames": n,
+            "windows": windows, "seconds": round(dt, 3),
+            "path": "host uint8 frames -> infer_video_depth(batch_size=32) -> host fp32 depth (PCIe both ways included)"}
 
 
 def cpu_baseline(encoder, H, W):

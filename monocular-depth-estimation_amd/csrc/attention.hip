@@ -22,14 +22,21 @@ __device__ __forceinline__ int v_off(int row, int col) { return row * 128 + ((co
 // rescale pass is skipped on almost every tile once the maximum has settled.
 constexpr float DEFER = 4.0f;
 
-__global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int n_tok, int heads) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int n_tok, int heads, int q_blocks) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int frame = blockIdx.y / heads, head = blockIdx.y % heads;
+    // Workgroups are handed to the 8 XCDs round-robin.  Renumber them so that each XCD works through a contiguous range of
+    // (frame, head, query block) triples: the query blocks of one (frame, head) then share that XCD's L2 copy of its K and V
+    // instead of every XCD fetching its own (q, r: bijective for any workgroup count).
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7;
+    const int per = nwg >> 3, rem = nwg & 7;
+    const int wg = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (blockIdx.x >> 3);
+    const int fh = wg / q_blocks, qb = wg - fh * q_blocks;
+    const int frame = fh / heads, head = fh - frame * heads;
     const int D = heads * 64, ld = 3 * D;
     const bf16* base = qkv + (size_t)frame * n_tok * ld + head * 64;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qb * 128 + wave * 32;
 
     // Q fragments (B operand of S^T = K Q^T): lane (r, h) holds Q[q0 + r][16 ks + 8 h + 0..7]
     bf16x8 qf[4];
@@ -171,9 +178,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
 
 extern "C" int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, void* stream) {
     if (!qkv || !out || frames <= 0 || n_tok <= 0 || heads <= 0) return VDA_EINVAL;
-    if ((long)frames * heads > 65535) return VDA_ESHAPE;
-    dim3 grid((n_tok + 127) / 128, frames * heads);
+    const int q_blocks = (n_tok + 127) / 128;
+    if ((long)frames * heads * q_blocks > 0x7fffffffL) return VDA_ESHAPE;
+    dim3 grid(frames * heads * q_blocks);
     hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const bf16*>(qkv), reinterpret_cast<bf16*>(out), n_tok, heads);
+                       reinterpret_cast<const bf16*>(qkv), reinterpret_cast<bf16*>(out), n_tok, heads, q_blocks);
     return hip_rc(hipGetLastError());
 }
