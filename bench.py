@@ -115,6 +115,8 @@ def main():
                                    "kernel": "gemm256_kernel<LINEAR,bf16> (encoder qkv/proj/fc1/fc2)",
                                    "launches": launches, "avg_launch_us": round(1e3 * ms / launches, 2),
                                    "avg_gflop_per_launch": round(flops / launches / 1e9, 3)}
+            if (args.encoder, H, W, T) == ("vitl", 518, 518, 32):
+                out["roofline"].update(pmc_traffic("gemm256_kernelILi0ELb0EDF16b"))
         if not args.no_end_to_end and world == 1:
             out["end_to_end"] = end_to_end(model, H, W)
         if not args.no_cpu_baseline:
@@ -123,6 +125,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel_substring):
+    """HBM-side bytes per launch of the dominant kernel on the flagship workload, from the committed counter passes
+    (`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` over this same command, one pass each; FETCH_SIZE doubled for
+    gfx950's 64-byte tally of 128-byte requests): counters cannot be collected from inside the timed process."""
+    path = os.path.join(ROOT, "profiles", "r1_step2_vitl518_hbm_traffic.json")
+    try:
+        rows = json.load(open(path))
+        row = next(r for r in rows if kernel_substring in r["kernel"])
+    except (OSError, StopIteration, ValueError):
+        return {}
+    return {"traffic": round(row["hbm_bytes_per_launch"]), "traffic_unit": "bytes per launch (fetch x2 + write)",
+            "traffic_source": "profiles/r1_step2_vitl518_hbm_traffic.json"}
 
 
 def end_to_end(model, H, W, n=98):
