@@ -105,9 +105,11 @@ int vda_layernorm(const float* x, void* out, const float* weight, const float* b
 /* ---------------------------------------------------------------------------------------------------------------
  * GroupNorm over NHWC half maps (dtype BF16 or F16): statistics per (frame, group) over hw * C/groups values, affine,
  * output in the same type.
- * `work` is caller-provided scratch of frames * groups * 16 bytes, 8-byte aligned (it is zeroed by the call).
+ * `work` is caller-provided scratch of frames * VDA_GROUPNORM_MAX_SPLITS * groups * 16 bytes, 8-byte aligned (partial sums
+ * per slice of a frame; no atomics are used, so results are bit-identical from run to run).  C <= 2048.
  * Replaces motion_module.py:110.
  * ------------------------------------------------------------------------------------------------------------- */
+#define VDA_GROUPNORM_MAX_SPLITS 64
 int vda_groupnorm(const void* x, void* out, const float* weight, const float* bias, void* work, int frames, int hw,
                   int C, int groups, float eps, int dtype, void* stream);
 

@@ -56,56 +56,66 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-// GroupNorm pass 1: grid (frames, splits).  Each block walks a slice of the frame's pixels; thread t owns the 8
-// channels [8*(t % (C/8)) ..] (so a thread stays inside one group when C/groups is even and >= ... see host check),
-// partial sums go to LDS per group, then one double atomicAdd pair per (frame, group, block).
+// GroupNorm pass 1: grid (frames, splits), 256 threads.  A block walks every splits-th slab of `ppb` pixels of its frame;
+// thread t < ppb * C/8 owns the 8 channels [8 (t % (C/8)) ..] of pixel row t / (C/8) of each slab and keeps PER-CHANNEL
+// fp32 sums in registers, so no accumulation order depends on scheduling.  The block then reduces them per group in a
+// fixed order (double) and stores one (sum, sum of squares) pair per (frame, split, group): pass 2 adds the splits in
+// order.  No atomics: the result is bit-identical from run to run.
 template <typename T>
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, double* __restrict__ sums, int hw,
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, double* __restrict__ partial, int hw,
                                                               int C, int groups) {
-    __shared__ float red[2 * 64];
+    __shared__ float ch_s[256][9], ch_q[256][9];      // [thread][channel of the thread], padded against bank conflicts
     const int frame = blockIdx.x;
-    const int cv = C / 8;                       // 8-channel vectors per pixel
+    const int cv = C / 8;                       // 8-channel vectors per pixel (host guarantees cv <= 256)
     const int cpg = C / groups;                 // channels per group
-    if (threadIdx.x < 2 * groups) red[threadIdx.x] = 0.f;
-    __syncthreads();
-    const size_t total = (size_t)hw * cv;
-    const T* xf = x + (size_t)frame * hw * C;
-    // a thread's vector index advances by a multiple of cv?  Not in general, so recompute the group per element.
-    for (size_t i = (size_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.y * blockDim.x) {
-        const int c0 = (int)(i % cv) * 8;
-        const typename Vec<T>::v8 v = *reinterpret_cast<const typename Vec<T>::v8*>(xf + i * 8);
-        if (cpg % 8 == 0) {
-            float s = 0.f, q = 0.f;
+    const int ppb = 256 / cv;                   // pixels per slab
+    const int t = threadIdx.x;
+    const int cvec = t % cv, prow = t / cv;
+    float s[8], q[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const float f = (float)v[k]; s += f; q += f * f; }
-            atomicAdd(&red[2 * (c0 / cpg)], s);
-            atomicAdd(&red[2 * (c0 / cpg) + 1], q);
-        } else {
+    for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; }
+    if (prow < ppb) {
+        const T* xf = x + (size_t)frame * hw * C + cvec * 8;
+        for (int p = blockIdx.y * ppb + prow; p < hw; p += gridDim.y * ppb) {
+            const typename Vec<T>::v8 v = *reinterpret_cast<const typename Vec<T>::v8*>(xf + (size_t)p * C);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float f = (float)v[k];
-                const int g = (c0 + k) / cpg;
-                atomicAdd(&red[2 * g], f);
-                atomicAdd(&red[2 * g + 1], f * f);
-            }
+            for (int k = 0; k < 8; ++k) { const float f = (float)v[k]; s[k] += f; q[k] += f * f; }
         }
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ch_s[t][k] = s[k]; ch_q[t][k] = q[k]; }
     __syncthreads();
-    if (threadIdx.x < 2 * groups) atomicAdd(&sums[(size_t)frame * 2 * groups + threadIdx.x], (double)red[threadIdx.x]);
+    if (t < groups) {
+        double gs = 0.0, gq = 0.0;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c)
+            for (int r = 0; r < ppb; ++r) {
+                gs += (double)ch_s[r * cv + (c >> 3)][c & 7];
+                gq += (double)ch_q[r * cv + (c >> 3)][c & 7];
+            }
+        double* dst = partial + (((size_t)frame * gridDim.y + blockIdx.y) * groups + t) * 2;
+        dst[0] = gs;
+        dst[1] = gq;
+    }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                               const float* __restrict__ w, const float* __restrict__ b,
-                                                              const double* __restrict__ sums, int hw, int C, int groups,
+                                                              const double* __restrict__ partial, int hw, int C, int groups,
                                                               float eps) {
     __shared__ float mean_s[64], rstd_s[64];
     const int frame = blockIdx.x;
     const int cpg = C / groups;
     if (threadIdx.x < groups) {
+        double gs = 0.0, gq = 0.0;
+        for (int sp = 0; sp < (int)gridDim.y; ++sp) {      // same split count as pass 1, added in order
+            const double* src = partial + (((size_t)frame * gridDim.y + sp) * groups + threadIdx.x) * 2;
+            gs += src[0];
+            gq += src[1];
+        }
         const double n = (double)hw * cpg;
-        const double mu = sums[(size_t)frame * 2 * groups + 2 * threadIdx.x] / n;
-        double var = sums[(size_t)frame * 2 * groups + 2 * threadIdx.x + 1] / n - mu * mu;
+        const double mu = gs / n;
+        double var = gq / n - mu * mu;
         if (var < 0) var = 0;
         mean_s[threadIdx.x] = (float)mu;
         rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
@@ -159,16 +169,14 @@ extern "C" int vda_layernorm(const float* x, void* out, const float* weight, con
 extern "C" int vda_groupnorm(const void* x, void* out, const float* weight, const float* bias, void* work, int frames,
                              int hw, int C, int groups, float eps, int dtype, void* stream) {
     if (!x || !out || !weight || !bias || !work || frames <= 0 || hw <= 0) return VDA_EINVAL;
-    if (groups <= 0 || groups > 64 || C % groups != 0 || C % 8 != 0) return VDA_ESHAPE;
+    if (groups <= 0 || groups > 64 || C % groups != 0 || C % 8 != 0 || C > 2048) return VDA_ESHAPE;
     if (((uintptr_t)work & 7) != 0) return VDA_ESHAPE;
     if (dtype != VDA_T_BF16 && dtype != VDA_T_F16) return VDA_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    double* sums = reinterpret_cast<double*>(work);
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * groups * frames, s);
-    if (e != hipSuccess) return (int)e;
+    double* sums = reinterpret_cast<double*>(work);       // [frame][split][group][2], every element written by pass 1
     const size_t total = (size_t)hw * (C / 8);
     int splits = (int)((total + 256 * 8 - 1) / (256 * 8));
-    if (splits > 64) splits = 64;
+    if (splits > VDA_GROUPNORM_MAX_SPLITS) splits = VDA_GROUPNORM_MAX_SPLITS;
     if (splits < 1) splits = 1;
     dim3 grid(frames, splits);
     if (dtype == VDA_T_F16) {

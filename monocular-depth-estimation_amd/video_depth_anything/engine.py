@@ -89,7 +89,7 @@ class Engine:
         hw = h * wd
         M = f * hw
         xf = x.reshape(M, C)
-        work = _empty((f * 32 * 2,), torch.float64, dev)
+        work = _empty((f * hip.GROUPNORM_MAX_SPLITS * 32 * 2,), torch.float64, dev)
         g = _empty((M, C), self.hdt, dev)
         hip.groupnorm(xf, g, m["gn_w"], m["gn_b"], work, f, hw, C, 32, 1e-6)
         hs = _empty((M, C), torch.float32, dev)

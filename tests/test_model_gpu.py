@@ -83,22 +83,72 @@ def test_no_cpu_path(vits):
         model(torch.zeros(1, 2, 3, 28, 28))
 
 
-def test_vitl_full_window_518_against_oracle_on_device():
-    """The flagship configuration (ViT-L, 1x32x3x518x518).  The oracle restatement is executed by torch in fp32 on the
-    GPU here (same code as the CPU oracle; the CPU run takes minutes at this size)."""
+@pytest.fixture(scope="module")
+def vitl():
     cfg = spec.MODEL_CONFIGS["vitl"]
     sd = {k: torch.from_numpy(v) for k, v in spec.synth_state_dict(**cfg, seed=1).items()}
     m = VideoDepthAnything(**cfg)
     m.load_state_dict(sd, strict=True)
-    m = m.to("cuda").eval()
-    x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 32, 3, 518, 518)).astype(np.float32)).cuda()
-    got = m(x).cpu().numpy()
     torch.backends.cuda.matmul.allow_tf32 = False
     torch.backends.cudnn.allow_tf32 = False
-    sd_dev = {k: v.cuda() for k, v in sd.items()}
-    want = O.forward(sd_dev, x, "vitl").cpu().numpy()
+    return m.to("cuda").eval(), {k: v.cuda() for k, v in sd.items()}
+
+
+def oracle_on_device(sd_dev, x, enc):
+    """The oracle restatement executed by torch in fp32 on the GPU (same code as the CPU oracle, which takes minutes at
+    these sizes)."""
+    return O.forward(sd_dev, x, enc).cpu().numpy()
+
+
+def test_vitl_full_window_518_against_oracle_on_device(vitl):
+    """The flagship configuration (ViT-L, 1x32x3x518x518)."""
+    m, sd_dev = vitl
+    x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 32, 3, 518, 518)).astype(np.float32)).cuda()
+    got = m(x).cpu().numpy()
+    want = oracle_on_device(sd_dev, x, "vitl")
     assert got.shape == want.shape == (1, 32, 518, 518)
     worst = max(O.max_rel_err(got[0, t], want[0, t]) for t in range(32))
     ar = O.abs_rel(got, want)
     print(f"vitl 518 full window: worst per-frame max_rel={worst:.3e} abs_rel={ar:.3e} depth range {want.min():.3f}..{want.max():.3f}")
+    assert worst <= MAX_REL and ar <= ABS_REL
+
+
+def test_vitl_wide_frame_518x924_against_oracle_on_device(vitl):
+    """The 16:9 network size of 720p / 1080p sources (37 x 66 patches: resampled positional table, 2443 tokens, every
+    GEMM with M and attention with a token count that are not multiples of the tiles)."""
+    m, sd_dev = vitl
+    x = torch.from_numpy(np.random.RandomState(3).standard_normal((1, 4, 3, 518, 924)).astype(np.float32)).cuda()
+    got = m(x).cpu().numpy()
+    want = oracle_on_device(sd_dev, x, "vitl")
+    worst = max(O.max_rel_err(got[0, t], want[0, t]) for t in range(4))
+    ar = O.abs_rel(got, want)
+    print(f"vitl 518x924 T=4: worst per-frame max_rel={worst:.3e} abs_rel={ar:.3e}")
+    assert worst <= MAX_REL and ar <= ABS_REL
+
+
+def test_vitl_full_window_is_deterministic_and_batch_consistent(vitl):
+    """Size-independent properties at the flagship size: the same window twice gives the same bits, and two windows
+    stacked on the batch axis give exactly what they give one at a time (windows never mix)."""
+    m, _ = vitl
+    rs = np.random.RandomState(11)
+    a = torch.from_numpy(rs.standard_normal((1, 32, 3, 518, 518)).astype(np.float32)).cuda()
+    b = torch.from_numpy(rs.standard_normal((1, 32, 3, 518, 518)).astype(np.float32)).cuda()
+    da, db = m(a).clone(), m(b).clone()
+    assert torch.equal(m(a), da)
+    both = m(torch.cat([a, b], 0))
+    assert both.shape == (2, 32, 518, 518)
+    assert torch.equal(both[0], da[0]) and torch.equal(both[1], db[0])
+    assert bool((da >= 0).all()) and bool(torch.isfinite(da).all())
+
+
+def test_vits_1036_against_oracle_on_device(vits):
+    """input_size 1036: 74 x 74 patches, 5477 tokens per frame (long attention rows, the largest positional resampling)."""
+    model, sd = vits
+    sd_dev = {k: v.cuda() for k, v in sd.items()}
+    x = torch.from_numpy(np.random.RandomState(5).standard_normal((1, 2, 3, 1036, 1036)).astype(np.float32)).cuda()
+    got = model(x).cpu().numpy()
+    want = oracle_on_device(sd_dev, x, "vits")
+    worst = max(O.max_rel_err(got[0, t], want[0, t]) for t in range(2))
+    ar = O.abs_rel(got, want)
+    print(f"vits 1036 T=2: worst per-frame max_rel={worst:.3e} abs_rel={ar:.3e}")
     assert worst <= MAX_REL and ar <= ABS_REL
