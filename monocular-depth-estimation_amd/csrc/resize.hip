@@ -20,48 +20,48 @@ __device__ __forceinline__ Lerp lerp_of(int dst, int in, int out) {
     return l;
 }
 
+// One workgroup per output row (frame, oy): the vertical taps are computed once per workgroup and all per-element index
+// arithmetic is 32-bit (a flat 64-bit index split by division costs more instructions than the 4 loads and the store).
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const T* __restrict__ x, T* __restrict__ out, int in_h,
-                                                            int in_w, int out_h, int out_w, int C, size_t total) {
-    const int cv = C / 8;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) * 8;
-        size_t pix = i / cv;
-        const int ox = (int)(pix % out_w);
-        pix /= out_w;
-        const int oy = (int)(pix % out_h);
-        const int f = (int)(pix / out_h);
-        const Lerp ly = lerp_of(oy, in_h, out_h), lx = lerp_of(ox, in_w, out_w);
-        typedef typename Vec<T>::v8 v8;
-        const T* base = x + (size_t)f * in_h * in_w * C + c;
-        const v8 a = *reinterpret_cast<const v8*>(base + ((size_t)ly.i0 * in_w + lx.i0) * C);
-        const v8 b = *reinterpret_cast<const v8*>(base + ((size_t)ly.i0 * in_w + lx.i1) * C);
-        const v8 cc = *reinterpret_cast<const v8*>(base + ((size_t)ly.i1 * in_w + lx.i0) * C);
-        const v8 d = *reinterpret_cast<const v8*>(base + ((size_t)ly.i1 * in_w + lx.i1) * C);
+                                                            int in_w, int out_h, int out_w, int C) {
+    typedef typename Vec<T>::v8 v8;
+    const unsigned cv = C / 8;
+    const int f = blockIdx.x / out_h, oy = blockIdx.x - f * out_h;
+    const Lerp ly = lerp_of(oy, in_h, out_h);
+    const T* row0 = x + ((size_t)f * in_h + ly.i0) * in_w * C;
+    const T* row1 = x + ((size_t)f * in_h + ly.i1) * in_w * C;
+    T* orow = out + (size_t)blockIdx.x * out_w * C;
+    const unsigned n = out_w * cv;
+    for (unsigned i = threadIdx.x; i < n; i += 256) {
+        const unsigned ox = i / cv, c = (i - ox * cv) * 8;
+        const Lerp lx = lerp_of((int)ox, in_w, out_w);
+        const v8 a = *reinterpret_cast<const v8*>(row0 + lx.i0 * C + c);
+        const v8 b = *reinterpret_cast<const v8*>(row0 + lx.i1 * C + c);
+        const v8 cc = *reinterpret_cast<const v8*>(row1 + lx.i0 * C + c);
+        const v8 d = *reinterpret_cast<const v8*>(row1 + lx.i1 * C + c);
         v8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float v = ly.w0 * (lx.w0 * (float)a[k] + lx.w1 * (float)b[k]) + ly.w1 * (lx.w0 * (float)cc[k] + lx.w1 * (float)d[k]);
             o[k] = (T)v;
         }
-        *reinterpret_cast<v8*>(out + i * 8) = o;
+        *reinterpret_cast<v8*>(orow + (size_t)i * 8) = o;
     }
 }
 
 __global__ __launch_bounds__(256) void bilinear_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int in_h,
-                                                           int in_w, int out_h, int out_w, int relu, size_t total) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % out_w);
-        size_t pix = i / out_w;
-        const int oy = (int)(pix % out_h);
-        const int f = (int)(pix / out_h);
-        const Lerp ly = lerp_of(oy, in_h, out_h), lx = lerp_of(ox, in_w, out_w);
-        const float* base = x + (size_t)f * in_h * in_w;
-        const float a = base[(size_t)ly.i0 * in_w + lx.i0], b = base[(size_t)ly.i0 * in_w + lx.i1];
-        const float c = base[(size_t)ly.i1 * in_w + lx.i0], d = base[(size_t)ly.i1 * in_w + lx.i1];
-        float v = ly.w0 * (lx.w0 * a + lx.w1 * b) + ly.w1 * (lx.w0 * c + lx.w1 * d);
+                                                           int in_w, int out_h, int out_w, int relu) {
+    const int f = blockIdx.x / out_h, oy = blockIdx.x - f * out_h;
+    const Lerp ly = lerp_of(oy, in_h, out_h);
+    const float* row0 = x + ((size_t)f * in_h + ly.i0) * in_w;
+    const float* row1 = x + ((size_t)f * in_h + ly.i1) * in_w;
+    float* orow = out + (size_t)blockIdx.x * out_w;
+    for (int ox = threadIdx.x; ox < out_w; ox += 256) {
+        const Lerp lx = lerp_of(ox, in_w, out_w);
+        float v = ly.w0 * (lx.w0 * row0[lx.i0] + lx.w1 * row0[lx.i1]) + ly.w1 * (lx.w0 * row1[lx.i0] + lx.w1 * row1[lx.i1]);
         if (relu) v = fmaxf(v, 0.f);
-        out[i] = v;
+        orow[ox] = v;
     }
 }
 
@@ -174,23 +174,24 @@ extern "C" int vda_bilinear_nhwc(const void* x, void* out, int frames, int in_h,
     if (!x || !out || frames <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || C <= 0) return VDA_EINVAL;
     if (C % 8 != 0) return VDA_ESHAPE;
     if (dtype != VDA_T_BF16 && dtype != VDA_T_F16) return VDA_EINVAL;
-    const size_t total = (size_t)frames * out_h * out_w * (C / 8);
+    if ((long)frames * out_h > 0x7fffffffL || (long)out_w * (C / 8) > 0x7fffffffL || (long)in_w * C > 0x7fffffffL) return VDA_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(frames * out_h);
     if (dtype == VDA_T_F16)
-        hipLaunchKernelGGL(bilinear_nhwc_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, reinterpret_cast<const f16*>(x),
-                           reinterpret_cast<f16*>(out), in_h, in_w, out_h, out_w, C, total);
+        hipLaunchKernelGGL(bilinear_nhwc_kernel<f16>, grid, dim3(256), 0, s, reinterpret_cast<const f16*>(x),
+                           reinterpret_cast<f16*>(out), in_h, in_w, out_h, out_w, C);
     else
-        hipLaunchKernelGGL(bilinear_nhwc_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, reinterpret_cast<const bf16*>(x),
-                           reinterpret_cast<bf16*>(out), in_h, in_w, out_h, out_w, C, total);
+        hipLaunchKernelGGL(bilinear_nhwc_kernel<bf16>, grid, dim3(256), 0, s, reinterpret_cast<const bf16*>(x),
+                           reinterpret_cast<bf16*>(out), in_h, in_w, out_h, out_w, C);
     return hip_rc(hipGetLastError());
 }
 
 extern "C" int vda_bilinear_f32(const float* x, float* out, int frames, int in_h, int in_w, int out_h, int out_w, int relu,
                                 void* stream) {
     if (!x || !out || frames <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return VDA_EINVAL;
-    const size_t total = (size_t)frames * out_h * out_w;
-    hipLaunchKernelGGL(bilinear_f32_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out,
-                       in_h, in_w, out_h, out_w, relu, total);
+    if ((long)frames * out_h > 0x7fffffffL) return VDA_ESHAPE;
+    hipLaunchKernelGGL(bilinear_f32_kernel, dim3(frames * out_h), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out,
+                       in_h, in_w, out_h, out_w, relu);
     return hip_rc(hipGetLastError());
 }
 
