@@ -142,7 +142,7 @@ def test_gemm_conv3x3_dot_tail():
     close(out.reshape(B, 1, h, w_), want, 1e-4, "conv+dot tail")
 
 
-@pytest.mark.parametrize("frames,n_tok,heads", [(2, 1370, 6), (3, 64, 2), (1, 129, 16), (2, 36, 1)])
+@pytest.mark.parametrize("frames,n_tok,heads", [(2, 1370, 6), (3, 64, 2), (1, 129, 16), (2, 36, 1), (1, 4100, 2), (1, 5477, 1)])
 def test_attention(frames, n_tok, heads):
     D = heads * 64
     qkv = rnd((frames, n_tok, 3 * D), 1)
@@ -153,11 +153,13 @@ def test_attention(frames, n_tok, heads):
     close(out, want, 1.2e-2, "attention")       # probabilities are rounded to bf16 before the second product
 
 
-def test_attention_sharp_softmax_rescale():
-    """One key dominates from the second K/V tile on: forces the running-max rescale branch."""
-    frames, n_tok, heads = 1, 200, 1
+@pytest.mark.parametrize("n_tok", [200, 4200])       # 32 and 64 queries per wave
+def test_attention_sharp_softmax_rescale(n_tok):
+    """One key dominates from a later K/V tile on: forces the running-max rescale branch."""
+    frames, heads = 1, 1
     qkv = rnd((frames, n_tok, 192), 2, 0.5)
     qkv[0, 150, 64:128] = qkv[0, 10, 0:64] * 12          # key 150 aligned with query 10
+    qkv[0, n_tok - 7, 64:128] = qkv[0, 45, 0:64] * 12    # and one in the last tile, for a query of the second block
     out = torch.empty((frames, n_tok, 64), dtype=BF, device=DEV)
     hip.attention(qkv, out, frames, n_tok, heads)
     q, k, v = qkv.float().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
