@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--height", type=int, default=518)
     ap.add_argument("--width", type=int, default=518)
     ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--precision", default="half", choices=["half", "fp32"],
+                    help="half: 16-bit activations (the headline); fp32: fp32 activations, three-term bf16 hi/lo products")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
@@ -62,6 +64,7 @@ def main():
     cfg = spec.MODEL_CONFIGS[args.encoder]
     model = VideoDepthAnything(**cfg)             # random-init weights of the named architecture (no checkpoints offline)
     model = model.to(dev).eval()
+    model.precision = args.precision
     T, H, W = args.frames, args.height, args.width
     x = torch.from_numpy(np.random.RandomState(rank).standard_normal((1, T, 3, H, W)).astype(np.float32)).to(dev)
 
@@ -92,15 +95,16 @@ def main():
     if rank == 0:
         fps = world * args.steps * T / dt
         out = {
-            "metric": "frames/sec at 518px (VDA-L, 32-frame windows)" if (args.encoder, H, W, T) == ("vitl", 518, 518, 32)
-            else f"frames/sec ({args.encoder}, {T}-frame windows at {H}x{W})",
+            "metric": "frames/sec at 518px (VDA-L, 32-frame windows)" if (args.encoder, H, W, T, args.precision) == ("vitl", 518, 518, 32, "half")
+            else f"frames/sec ({args.encoder}, {T}-frame windows at {H}x{W}, precision {args.precision})",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16" if args.precision == "half" else "f32 (3 x bf16 hi/lo MFMA passes)", "data": "synthetic",
             "config": {"workload": f"Video-Depth-Anything-{'Large (ViT-L)' if args.encoder == 'vitl' else 'Small (ViT-S)'} "
                                    f"forward, 1x{T}x3x{H}x{W} window resident in HBM, random-init weights",
                        "windows_per_step_per_gpu": 1, "parallelism": f"window-parallel x{world}",
-                       "operands": "encoder bf16 MFMA, head fp16 MFMA, fp32 accumulate"},
+                       "operands": "encoder bf16 MFMA, head fp16 MFMA, fp32 accumulate" if args.precision == "half"
+                       else "fp32 activations; every product hi*hi + lo*hi + hi*lo on bf16 MFMA, fp32 accumulate"},
         }
         gf = GFLOP_PER_FRAME.get((args.encoder, H, W))
         if gf:
@@ -115,7 +119,7 @@ def main():
                                    "kernel": "gemm256_kernel<LINEAR,bf16> (encoder qkv/proj/fc1/fc2)",
                                    "launches": launches, "avg_launch_us": round(1e3 * ms / launches, 2),
                                    "avg_gflop_per_launch": round(flops / launches / 1e9, 3)}
-            if (args.encoder, H, W, T) == ("vitl", 518, 518, 32):
+            if (args.encoder, H, W, T, args.precision) == ("vitl", 518, 518, 32, "half"):
                 out["roofline"].update(pmc_traffic("gemm256_kernelILi0ELb0EDF16b"))
         if not args.no_end_to_end and world == 1:
             out["end_to_end"] = end_to_end(model, H, W)

@@ -10,6 +10,12 @@
  *     failed launch; nothing throws or aborts;
  *   - "bf16" is the raw 16-bit brain-float pattern (uint16_t); activations are channels-last ("NHWC" = [frame, y, x, c]),
  *     i.e. every feature map is a row-major [rows = frame*h*w + y*w + x, channels] matrix.
+ *
+ * Two storage modes share these entry points.  The default keeps activations in 16 bits.  The fp32 mode (the
+ * reference's fp32=True, video_depth.py:67,136) keeps every activation in fp32 (dtype / out_type VDA_T_F32 below) and
+ * still multiplies on the bf16 matrix cores: vda_split3 turns an fp32 operand into bf16 triples [hi | lo | hi], weights
+ * are packed [hi | hi | lo], and one vda_gemm pass over K' = 3K accumulates hi*hi + lo*hi + hi*lo in fp32
+ * (about 2^-16 relative per product, at a third of the bf16 rate instead of the sixteenth of the fp32 matrix cores).
  */
 #ifndef VDA_HIP_H
 #define VDA_HIP_H
@@ -64,14 +70,14 @@ typedef struct VdaGemmArgs {
     const float* bias;    /* [N] or NULL                                                      */
     const float* gamma;   /* [N] or NULL                                                      */
     const void* resid;    /* resid_type [M][ldr] or NULL; may alias out                        */
-    const void* resid2;   /* ab_type [M][ldr2] or NULL                                        */
+    const void* resid2;   /* resid_type [M][ldr2] or NULL (a second residual needs a first)    */
     const void* zeros;    /* >= 256 B of zeros (CONV3 only)                                    */
     const float* dot_w;   /* [N] (EPI_DOT only)                                                */
     float dot_b;
     int M, N, K;          /* K % 64 == 0                                                      */
     int lda, ldc, ldr, ldr2;
     int a_mode, act, epi, out_type, resid_type;
-    int ab_type;          /* VDA_T_BF16 or VDA_T_F16: element type of a, w and resid2          */
+    int ab_type;          /* VDA_T_BF16 or VDA_T_F16: element type of a and w                  */
     int relu_in;          /* apply ReLU to A while loading (pre-activation conv, util/blocks.py:78) */
     int in_h, in_w, cin, out_h, out_w, stride;   /* CONV3 geometry; cin % 64 == 0, M = imgs*out_h*out_w */
     int ct_h, ct_w, ct_k, ct_c;                  /* EPI_CONVT geometry                                   */
@@ -84,14 +90,16 @@ int vda_gemm(const VdaGemmArgs* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Multi-head self-attention over the tokens of each frame, head dim 64, no mask, flash-style (scores never leave
- * the CU).  qkv: bf16 [frames][n_tok][3*heads*64] laid out [q | k | v] x [head][64] as produced by the fused QKV
- * projection, q already multiplied by 64^-1/2; out: bf16 [frames][n_tok][heads*64].
+ * the CU).  qkv: [frames][n_tok][3*heads*64] laid out [q | k | v] x [head][64] as produced by the fused QKV
+ * projection, q already multiplied by 64^-1/2; out: [frames][n_tok][heads*64]; both of type dtype.
+ * dtype VDA_T_BF16: bf16 operands.  dtype VDA_T_F32: fp32 in and out; q, k, v and the probabilities are split into
+ * bf16 hi/lo pairs on the fly and every product is the three-term hi/lo sum.
  * Replaces attention.py:51-59 of the reference (dinov2_layers).
  * ------------------------------------------------------------------------------------------------------------- */
-int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, void* stream);
+int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * Row LayerNorm (biased variance, eps inside the sqrt): fp32 rows in, half rows out (out_type BF16 or F16).
+ * Row LayerNorm (biased variance, eps inside the sqrt): fp32 rows in, rows of out_type (BF16, F16 or F32) out.
  * Output row r reads input row (r / rows_per_group) * in_group + in_skip + r % rows_per_group, which drops the class
  * token when taking the encoder taps (dinov2.py:310-312); with rows_per_group == in_group and in_skip == 0 it is the
  * identity map.  If pe != NULL, pe[((r / pe_hw) % pe_T)][c] (fp32 [pe_T][C]) is added after the affine step: the
@@ -103,7 +111,7 @@ int vda_layernorm(const float* x, void* out, const float* weight, const float* b
                   void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * GroupNorm over NHWC half maps (dtype BF16 or F16): statistics per (frame, group) over hw * C/groups values, affine,
+ * GroupNorm over NHWC maps (dtype BF16, F16 or F32): statistics per (frame, group) over hw * C/groups values, affine,
  * output in the same type.
  * `work` is caller-provided scratch of frames * VDA_GROUPNORM_MAX_SPLITS * groups * 16 bytes, 8-byte aligned (partial sums
  * per slice of a frame; no atomics are used, so results are bit-identical from run to run).  C <= 2048.
@@ -115,7 +123,7 @@ int vda_groupnorm(const void* x, void* out, const float* weight, const float* bi
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Bilinear resampling with align_corners=True (src = dst * (in-1)/(out-1)).
- * vda_bilinear_nhwc: half [frames][in_h][in_w][C] -> half [frames][out_h][out_w][C] (dtype BF16 or F16)   (util/blocks.py:156-158,
+ * vda_bilinear_nhwc: [frames][in_h][in_w][C] -> [frames][out_h][out_w][C] of dtype BF16, F16 or F32   (util/blocks.py:156-158,
  *   dpt_temporal.py:94-96).  C % 8 == 0.
  * vda_bilinear_f32: fp32 single-channel maps [frames][in_h][in_w] -> [frames][out_h][out_w], optional ReLU
  *   (video_depth.py:63-64, 142).
@@ -126,13 +134,22 @@ int vda_bilinear_f32(const float* x, float* out, int frames, int in_h, int in_w,
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Patch embedding front end.
- * vda_im2col_patch14: fp32 NCHW frames [frames][3][H][W] -> bf16 rows [frames*hp*wp][ldk], k = c*196 + ky*14 + kx
+ * vda_im2col_patch14: fp32 NCHW frames [frames][3][H][W] -> rows [frames*hp*wp][ldk] of out_type BF16 or F32, k = c*196 + ky*14 + kx
  *   (the flattening order of the conv weight [D][3][14][14]), columns 588..ldk-1 zero.  ldk % 64 == 0, ldk >= 588.
  * vda_assemble_tokens: x[f][0] = cls + pos[0]; x[f][1+p] = tok[f*hw+p] + pos[1+p]  (fp32)   (dinov2.py:218-219).
  * Replaces patch_embed.py:76-78 together with vda_gemm.
  * ------------------------------------------------------------------------------------------------------------- */
-int vda_im2col_patch14(const float* x, void* out, int frames, int H, int W, int ldk, void* stream);
+int vda_im2col_patch14(const float* x, void* out, int frames, int H, int W, int ldk, int out_type, void* stream);
 int vda_assemble_tokens(const float* tok, const float* cls, const float* pos, float* x, int frames, int hw, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * fp32 mode operand split: x fp32 [rows][ldx] (first C columns used, C % 4 == 0) -> out bf16 [rows][3*Cp], segments
+ * [hi | lo | hi] of Cp columns each (Cp % 64 == 0, columns C..Cp-1 zero), hi = bf16(v), lo = bf16(v - hi); relu != 0
+ * applies max(v, 0) first (the pre-activation of util/blocks.py:78, which cannot be applied to hi and lo separately).
+ * For an NHWC image rows = pixels and the result is an image with 3*Cp channels: the CONV3 operand for weights packed
+ * [Cout][9][hi | hi | lo].  No counterpart in the reference (its fp32 path multiplies in fp32).
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int relu, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Frame preprocessing: uint8 RGB frames [frames][h0][w0][3] -> fp32 [frames][3][H][W]: x/255, bicubic resize with
@@ -143,8 +160,8 @@ int vda_preprocess_u8(const uint8_t* frames_u8, float* out, int frames, int h0, 
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Temporal self-attention: for every (batch, spatial position, head) a softmax(q k^T * scale) v over the T <= 32
- * frames.  qkv: half rows ordered (batch, frame, position), each row [q | k | v] x [head][hd]; out: half, same row
- * order, [head][hd] (dtype BF16 or F16 for both).  Replaces motion_module.py:232,279-284,295 + motion_module/attention.py:93-111,182-211.
+ * frames.  qkv: rows ordered (batch, frame, position), each row [q | k | v] x [head][hd]; out: same row order,
+ * [head][hd] (dtype BF16, F16 or F32 for both; the arithmetic is fp32 in every case).  Replaces motion_module.py:232,279-284,295 + motion_module/attention.py:93-111,182-211.
  * ------------------------------------------------------------------------------------------------------------- */
 int vda_temporal_attention(const void* qkv, void* out, int batch, int T, int hw, int heads, int hd, float scale, int dtype,
                            void* stream);

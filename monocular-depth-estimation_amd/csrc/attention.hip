@@ -192,10 +192,193 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
     }
 }
 
+// fp32 storage mode: q, k, v and the output are fp32.  K and V tiles are split into bf16 hi/lo images while they are
+// staged (registers -> LDS), q and the probabilities are split in registers, and every product is the three-term sum
+// hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation.  Same structure as attn_kernel<1> otherwise.
+__global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n_tok,
+                                                            int heads, int q_blocks) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 32768];      // per buffer: K hi, K lo, V hi, V lo (8 KiB each)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7;
+    const int per = nwg >> 3, rem = nwg & 7;
+    const int wg = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (blockIdx.x >> 3);
+    const int fh = wg / q_blocks, qb = wg - fh * q_blocks;
+    const int frame = fh / heads, head = fh - frame * heads;
+    const int D = heads * 64, ld = 3 * D;
+    const float* base = qkv + (size_t)frame * n_tok * ld + head * 64;
+    const int q0 = qb * 128 + wave * 32;
+
+    auto split8 = [](const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bf16 x, y;
+            split_bf16(a[k], x, y); hi[k] = x; lo[k] = y;
+            split_bf16(b[k], x, y); hi[4 + k] = x; lo[4 + k] = y;
+        }
+    };
+
+    bf16x8 qhi[4], qlo[4];
+    {
+        const float* qrow = base + (size_t)min(q0 + r, n_tok - 1) * ld + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            split8(*reinterpret_cast<const f32x4*>(qrow + 16 * ks), *reinterpret_cast<const f32x4*>(qrow + 16 * ks + 4), qhi[ks], qlo[ks]);
+    }
+
+    const int srow = tid >> 3, sc = tid & 7;
+    const float* kbase = base + D + sc * 8;
+    const float* vbase = base + 2 * D + sc * 8;
+    f32x4 kreg[2][2], vreg[2][2];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t row = (size_t)min(kt * 64 + i * 32 + srow, n_tok - 1) * ld;
+            kreg[i][0] = *reinterpret_cast<const f32x4*>(kbase + row);
+            kreg[i][1] = *reinterpret_cast<const f32x4*>(kbase + row + 4);
+            vreg[i][0] = *reinterpret_cast<const f32x4*>(vbase + row);
+            vreg[i][1] = *reinterpret_cast<const f32x4*>(vbase + row + 4);
+        }
+    };
+    auto write_tile = [&](int buf) {
+        char* b0 = smem + buf * 32768;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = i * 32 + srow;
+            bf16x8 hi, lo;
+            split8(kreg[i][0], kreg[i][1], hi, lo);
+            *reinterpret_cast<bf16x8*>(b0 + tile_off(row, sc)) = hi;
+            *reinterpret_cast<bf16x8*>(b0 + 8192 + tile_off(row, sc)) = lo;
+            split8(vreg[i][0], vreg[i][1], hi, lo);
+            *reinterpret_cast<bf16x8*>(b0 + 16384 + v_off(row, sc * 8)) = hi;
+            *reinterpret_cast<bf16x8*>(b0 + 24576 + v_off(row, sc * 8)) = lo;
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nkt = (n_tok + 63) / 64;
+    load_tile(0);
+    write_tile(0);
+    __syncthreads();
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int tcol = 16 * ((lane >> 4) & 1) + 4 * tp;
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const char* kh = smem + cur * 32768;
+        const char* kl = kh + 8192;
+        const char* vh = kh + 16384;
+        const char* vl = kh + 24576;
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kbk][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = tile_off(32 * kbk + r, 2 * ks + h);
+                const bf16x8 khi = *reinterpret_cast<const bf16x8*>(kh + off);
+                const bf16x8 klo = *reinterpret_cast<const bf16x8*>(kl + off);
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qhi[ks], s[kbk], 0, 0, 0);
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qlo[ks], s[kbk], 0, 0, 0);
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qhi[ks], s[kbk], 0, 0, 0);
+            }
+        }
+        if (kt == nkt - 1) {
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 64 + 32 * kbk + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= n_tok) s[kbk][i] = -INFINITY;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (__builtin_amdgcn_ballot_w64(mx - m_run > DEFER) != 0) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        }
+        const float mneg = -m_run * LOG2E;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 ph[2][2], pl[2][2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = exp2f(fmaf(s[kbk][i], LOG2E, mneg));       // full-precision exp2 in this mode
+                ps[i & 3] += pv;
+                bf16 x, y;
+                split_bf16(pv, x, y);
+                ph[kbk][i >> 3][i & 7] = x;
+                pl[kbk][i >> 3][i & 7] = y;
+            }
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int k0 = 32 * kbk + 16 * s2 + 4 * h + tq;
+                    const int o0 = v_off(k0, 32 * db + tcol), o1 = v_off(k0 + 8, 32 * db + tcol);
+                    const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vh + o0));
+                    const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vh + o1));
+                    const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vl + o0));
+                    const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vl + o1));
+                    const bf16x8 vhi = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    const bf16x8 vlo = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlo, ph[kbk][s2], o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vhi, pl[kbk][s2], o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vhi, ph[kbk][s2], o[db], 0, 0, 0);
+                }
+
+        if (kt + 1 < nkt) write_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + r;
+    if (q < n_tok) {
+        float* orow = out + ((size_t)frame * n_tok + q) * D + head * 64 + 4 * h;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(orow + 32 * db + 8 * g) = v;
+            }
+    }
+}
+
 }  // namespace
 
-extern "C" int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, void* stream) {
+extern "C" int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, int dtype, void* stream) {
     if (!qkv || !out || frames <= 0 || n_tok <= 0 || heads <= 0) return VDA_EINVAL;
+    if (dtype != VDA_T_BF16 && dtype != VDA_T_F32) return VDA_EINVAL;
+    if (dtype == VDA_T_F32) {
+        const int qb = (n_tok + 127) / 128;
+        if ((long)frames * heads * qb > 0x7fffffffL) return VDA_ESHAPE;
+        hipLaunchKernelGGL(attn_split_kernel, dim3(frames * heads * qb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const float*>(qkv), reinterpret_cast<float*>(out), n_tok, heads, qb);
+        return hip_rc(hipGetLastError());
+    }
     // 64 queries per wave only for long sequences (measured, 32 frames x 16 heads: 5477 tokens +3 %, 1370 tokens -3 %: there
     // the third wave per SIMD that the smaller register footprint allows is worth more than the halved LDS traffic)
     const int nqb = n_tok >= 4096 ? 2 : 1;

@@ -12,6 +12,7 @@ typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -49,9 +50,17 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return x * (x >= 0.f ? 1.0f - h : h);
 }
 
-// 16-bit storage types: vectors of 4 / 8 elements per type
+// storage types: vectors of 4 / 8 elements per type (float: the fp32 storage mode)
 template <typename T> struct Vec;
 template <> struct Vec<bf16> { typedef bf16x4 v4; typedef bf16x8 v8; };
 template <> struct Vec<f16> { typedef f16x4 v4; typedef f16x8 v8; };
+template <> struct Vec<float> { typedef f32x4 v4; typedef f32x8 v8; };
+
+// hi/lo split of an fp32 value into two bf16: v = hi + lo up to 2^-17 |v|.  Three bf16 MFMA products
+// (hi*hi + lo*hi + hi*lo, fp32 accumulation) then reproduce an fp32 product to about 2^-16 relative.
+__device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
+    hi = (bf16)v;
+    lo = (bf16)(v - (float)hi);
+}
 
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }

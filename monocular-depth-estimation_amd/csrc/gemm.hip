@@ -163,6 +163,7 @@ extern "C" int vda_gemm(const VdaGemmArgs* args, void* stream) {
     if (a.K % BK != 0 || a.N % 4 != 0 || a.ldc % 4 != 0) return VDA_ESHAPE;
     if (a.resid_type != VDA_T_NONE && (!a.resid || a.ldr % 4 != 0)) return VDA_EINVAL;
     if (a.resid2 && a.ldr2 % 4 != 0) return VDA_ESHAPE;
+    if (a.resid2 && a.resid_type == VDA_T_NONE) return VDA_EINVAL;
     if (a.a_mode == VDA_A_CONV3) {
         if (!a.zeros || a.cin <= 0 || a.cin % BK != 0 || a.K != 9 * a.cin) return VDA_ESHAPE;
         if (a.stride < 1 || a.out_h <= 0 || a.out_w <= 0 || a.M % (a.out_h * a.out_w) != 0) return VDA_ESHAPE;

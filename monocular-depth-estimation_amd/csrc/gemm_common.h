@@ -124,7 +124,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
                 v *= gam[j];
                 if (m < p.M && n < p.N) {
                     if (p.resid_type != VDA_T_NONE) v += load4(p.resid, p.resid_type, (size_t)m * p.ldr + n);
-                    if (p.resid2) v += load4(p.resid2, p.ab_type, (size_t)m * p.ldr2 + n);
+                    if (p.resid2) v += load4(p.resid2, p.resid_type, (size_t)m * p.ldr2 + n);
                 }
                 store4(srow, p.out_type, j * 16 + fq * 4, v);
             }
@@ -237,7 +237,7 @@ __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)
             }
             v *= g;
             if (p.resid_type != VDA_T_NONE) v += load4(p.resid, p.resid_type, (size_t)m * p.ldr + n);
-            if (p.resid2) v += load4(p.resid2, p.ab_type, (size_t)m * p.ldr2 + n);
+            if (p.resid2) v += load4(p.resid2, p.resid_type, (size_t)m * p.ldr2 + n);
             size_t idx;
             if (p.epi == VDA_EPI_CONVT) {
                 const int iy = m / p.ct_w, x = m - iy * p.ct_w;     // iy = img * ct_h + y

@@ -146,7 +146,7 @@ extern "C" int vda_layernorm(const float* x, void* out, const float* weight, con
     if (!x || !out || !weight || !bias || rows <= 0 || C <= 0) return VDA_EINVAL;
     if (C % 4 != 0 || C > 2048 || rows_per_group <= 0 || in_group < rows_per_group + in_skip) return VDA_ESHAPE;
     if (pe && (pe_hw <= 0 || pe_T <= 0)) return VDA_EINVAL;
-    if (out_type != VDA_T_BF16 && out_type != VDA_T_F16) return VDA_EINVAL;
+    if (out_type != VDA_T_BF16 && out_type != VDA_T_F16 && out_type != VDA_T_F32) return VDA_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((rows + 3) / 4), block(256);
 #define LN_LAUNCH(V)                                                                                                       \
@@ -154,6 +154,9 @@ extern "C" int vda_layernorm(const float* x, void* out, const float* weight, con
         if (out_type == VDA_T_F16)                                                                                         \
             hipLaunchKernelGGL((layernorm_kernel<V, f16>), grid, block, 0, s, x, reinterpret_cast<f16*>(out), weight, bias, \
                                rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T);                          \
+        else if (out_type == VDA_T_F32)                                                                                    \
+            hipLaunchKernelGGL((layernorm_kernel<V, float>), grid, block, 0, s, x, reinterpret_cast<float*>(out), weight,  \
+                               bias, rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T);                    \
         else                                                                                                               \
             hipLaunchKernelGGL((layernorm_kernel<V, bf16>), grid, block, 0, s, x, reinterpret_cast<bf16*>(out), weight,    \
                                bias, rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T);                    \
@@ -171,7 +174,7 @@ extern "C" int vda_groupnorm(const void* x, void* out, const float* weight, cons
     if (!x || !out || !weight || !bias || !work || frames <= 0 || hw <= 0) return VDA_EINVAL;
     if (groups <= 0 || groups > 64 || C % groups != 0 || C % 8 != 0 || C > 2048) return VDA_ESHAPE;
     if (((uintptr_t)work & 7) != 0) return VDA_ESHAPE;
-    if (dtype != VDA_T_BF16 && dtype != VDA_T_F16) return VDA_EINVAL;
+    if (dtype != VDA_T_BF16 && dtype != VDA_T_F16 && dtype != VDA_T_F32) return VDA_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     double* sums = reinterpret_cast<double*>(work);       // [frame][split][group][2], every element written by pass 1
     const size_t total = (size_t)hw * (C / 8);
@@ -179,14 +182,15 @@ extern "C" int vda_groupnorm(const void* x, void* out, const float* weight, cons
     if (splits > VDA_GROUPNORM_MAX_SPLITS) splits = VDA_GROUPNORM_MAX_SPLITS;
     if (splits < 1) splits = 1;
     dim3 grid(frames, splits);
-    if (dtype == VDA_T_F16) {
-        hipLaunchKernelGGL(groupnorm_stats_kernel<f16>, grid, dim3(256), 0, s, reinterpret_cast<const f16*>(x), sums, hw, C, groups);
-        hipLaunchKernelGGL(groupnorm_apply_kernel<f16>, grid, dim3(256), 0, s, reinterpret_cast<const f16*>(x),
-                           reinterpret_cast<f16*>(out), weight, bias, sums, hw, C, groups, eps);
-    } else {
-        hipLaunchKernelGGL(groupnorm_stats_kernel<bf16>, grid, dim3(256), 0, s, reinterpret_cast<const bf16*>(x), sums, hw, C, groups);
-        hipLaunchKernelGGL(groupnorm_apply_kernel<bf16>, grid, dim3(256), 0, s, reinterpret_cast<const bf16*>(x),
-                           reinterpret_cast<bf16*>(out), weight, bias, sums, hw, C, groups, eps);
-    }
+#define GN_LAUNCH(TT)                                                                                                     \
+    do {                                                                                                                  \
+        hipLaunchKernelGGL(groupnorm_stats_kernel<TT>, grid, dim3(256), 0, s, reinterpret_cast<const TT*>(x), sums, hw, C, groups); \
+        hipLaunchKernelGGL(groupnorm_apply_kernel<TT>, grid, dim3(256), 0, s, reinterpret_cast<const TT*>(x),             \
+                           reinterpret_cast<TT*>(out), weight, bias, sums, hw, C, groups, eps);                          \
+    } while (0)
+    if (dtype == VDA_T_F16) GN_LAUNCH(f16);
+    else if (dtype == VDA_T_F32) GN_LAUNCH(float);
+    else GN_LAUNCH(bf16);
+#undef GN_LAUNCH
     return hip_rc(hipGetLastError());
 }

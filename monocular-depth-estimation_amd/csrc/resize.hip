@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void bilinear_f32_kernel(const float* __restri
 }
 
 // One thread per 8 output columns of an im2col row.  k = c*196 + ky*14 + kx.
-__global__ __launch_bounds__(256) void im2col_patch14_kernel(const float* __restrict__ x, bf16* __restrict__ out, int H, int W,
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_patch14_kernel(const float* __restrict__ x, T* __restrict__ out, int H, int W,
                                                              int hp, int wp, int ldk, size_t total) {
     const int kv = ldk / 8;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void im2col_patch14_kernel(const float* __rest
         row /= wp;
         const int py = (int)(row % hp);
         const int f = (int)(row / hp);
-        bf16x8 o;
+        typename Vec<T>::v8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + j;
@@ -86,9 +87,9 @@ __global__ __launch_bounds__(256) void im2col_patch14_kernel(const float* __rest
                 const int ky = rem / 14, kx = rem - ky * 14;
                 v = x[(((size_t)f * 3 + c) * H + py * 14 + ky) * W + px * 14 + kx];
             }
-            o[j] = (bf16)v;
+            o[j] = (T)v;
         }
-        *reinterpret_cast<bf16x8*>(out + i * 8) = o;
+        *reinterpret_cast<typename Vec<T>::v8*>(out + i * 8) = o;
     }
 }
 
@@ -160,6 +161,36 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
     }
 }
 
+// fp32 rows -> bf16 rows of three segments [hi | lo | hi] (each Cp wide, zero beyond C): the A operand of a GEMM whose
+// weight rows are packed [hi | hi | lo], so that one bf16 MFMA pass over K' = 3 Cp accumulates hi*hi + lo*hi + hi*lo.
+// One workgroup per 4 rows; 32-bit index arithmetic inside a row.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, bf16* __restrict__ out, long rows, int C,
+                                                     int ldx, int Cp, int relu) {
+    const long row0 = (long)blockIdx.x * 4;
+    const int cv = Cp / 4;
+    for (int i = threadIdx.x; i < 4 * cv; i += 256) {
+        const int r = i / cv, c = (i - r * cv) * 4;
+        const long row = row0 + r;
+        if (row >= rows) break;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < C) v = *reinterpret_cast<const f32x4*>(x + row * ldx + c);      // C % 4 == 0
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f = v[k];
+            if (relu) f = fmaxf(f, 0.f);
+            bf16 h, l;
+            split_bf16(f, h, l);
+            hi[k] = h;
+            lo[k] = l;
+        }
+        bf16* o = out + row * (3L * Cp) + c;
+        *reinterpret_cast<bf16x4*>(o) = hi;
+        *reinterpret_cast<bf16x4*>(o + Cp) = lo;
+        *reinterpret_cast<bf16x4*>(o + 2 * Cp) = hi;
+    }
+}
+
 inline int grid_for(size_t total) {
     size_t g = (total + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
@@ -173,13 +204,16 @@ extern "C" int vda_bilinear_nhwc(const void* x, void* out, int frames, int in_h,
                                  int dtype, void* stream) {
     if (!x || !out || frames <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || C <= 0) return VDA_EINVAL;
     if (C % 8 != 0) return VDA_ESHAPE;
-    if (dtype != VDA_T_BF16 && dtype != VDA_T_F16) return VDA_EINVAL;
+    if (dtype != VDA_T_BF16 && dtype != VDA_T_F16 && dtype != VDA_T_F32) return VDA_EINVAL;
     if ((long)frames * out_h > 0x7fffffffL || (long)out_w * (C / 8) > 0x7fffffffL || (long)in_w * C > 0x7fffffffL) return VDA_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(frames * out_h);
     if (dtype == VDA_T_F16)
         hipLaunchKernelGGL(bilinear_nhwc_kernel<f16>, grid, dim3(256), 0, s, reinterpret_cast<const f16*>(x),
                            reinterpret_cast<f16*>(out), in_h, in_w, out_h, out_w, C);
+    else if (dtype == VDA_T_F32)
+        hipLaunchKernelGGL(bilinear_nhwc_kernel<float>, grid, dim3(256), 0, s, reinterpret_cast<const float*>(x),
+                           reinterpret_cast<float*>(out), in_h, in_w, out_h, out_w, C);
     else
         hipLaunchKernelGGL(bilinear_nhwc_kernel<bf16>, grid, dim3(256), 0, s, reinterpret_cast<const bf16*>(x),
                            reinterpret_cast<bf16*>(out), in_h, in_w, out_h, out_w, C);
@@ -195,13 +229,26 @@ extern "C" int vda_bilinear_f32(const float* x, float* out, int frames, int in_h
     return hip_rc(hipGetLastError());
 }
 
-extern "C" int vda_im2col_patch14(const float* x, void* out, int frames, int H, int W, int ldk, void* stream) {
+extern "C" int vda_im2col_patch14(const float* x, void* out, int frames, int H, int W, int ldk, int out_type, void* stream) {
     if (!x || !out || frames <= 0 || H <= 0 || W <= 0) return VDA_EINVAL;
+    if (out_type != VDA_T_BF16 && out_type != VDA_T_F32) return VDA_EINVAL;
     if (H % 14 != 0 || W % 14 != 0 || ldk % 64 != 0 || ldk < 588) return VDA_ESHAPE;
     const int hp = H / 14, wp = W / 14;
     const size_t total = (size_t)frames * hp * wp * (ldk / 8);
-    hipLaunchKernelGGL(im2col_patch14_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                       reinterpret_cast<bf16*>(out), H, W, hp, wp, ldk, total);
+    if (out_type == VDA_T_F32)
+        hipLaunchKernelGGL(im2col_patch14_kernel<float>, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           x, reinterpret_cast<float*>(out), H, W, hp, wp, ldk, total);
+    else
+        hipLaunchKernelGGL(im2col_patch14_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           x, reinterpret_cast<bf16*>(out), H, W, hp, wp, ldk, total);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int relu, void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0) return VDA_EINVAL;
+    if (C % 4 != 0 || Cp % 64 != 0 || Cp < C || ldx < C || ldx % 4 != 0 || (rows + 3) / 4 > 0x7fffffffL) return VDA_ESHAPE;
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                       reinterpret_cast<bf16*>(out), rows, C, ldx, Cp, relu);
     return hip_rc(hipGetLastError());
 }
 

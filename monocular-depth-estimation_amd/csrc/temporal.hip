@@ -100,7 +100,7 @@ extern "C" int vda_temporal_attention(const void* qkv, void* out, int batch, int
                                       int dtype, void* stream) {
     if (!qkv || !out || batch <= 0 || T <= 0 || hw <= 0 || heads <= 0) return VDA_EINVAL;
     if (T > 32) return VDA_ESHAPE;
-    if (dtype != VDA_T_BF16 && dtype != VDA_T_F16) return VDA_EINVAL;
+    if (dtype != VDA_T_BF16 && dtype != VDA_T_F16 && dtype != VDA_T_F32) return VDA_EINVAL;
     const long blocks = (long)batch * hw * heads;
     if (blocks > 0x7fffffffL) return VDA_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -110,6 +110,9 @@ extern "C" int vda_temporal_attention(const void* qkv, void* out, int batch, int
         if (dtype == VDA_T_F16)                                                                                          \
             hipLaunchKernelGGL((temporal_attn_kernel<H, f16>), dim3((unsigned)blocks), dim3(64), 0, s,                    \
                                reinterpret_cast<const f16*>(qkv), reinterpret_cast<f16*>(out), T, hw, heads, sl);        \
+        else if (dtype == VDA_T_F32)                                                                                     \
+            hipLaunchKernelGGL((temporal_attn_kernel<H, float>), dim3((unsigned)blocks), dim3(64), 0, s,                  \
+                               reinterpret_cast<const float*>(qkv), reinterpret_cast<float*>(out), T, hw, heads, sl);    \
         else                                                                                                             \
             hipLaunchKernelGGL((temporal_attn_kernel<H, bf16>), dim3((unsigned)blocks), dim3(64), 0, s,                   \
                                reinterpret_cast<const bf16*>(qkv), reinterpret_cast<bf16*>(out), T, hw, heads, sl);      \

@@ -6,6 +6,9 @@ Layouts in HBM (T frames, hp x wp patches, N = hp*wp + 1 tokens, D embed dim):
                              Linear is a plain GEMM on the same buffer and the temporal modules need no transposes;
   * temporal hidden state    fp32 [frame][position][C];
   * depth                    fp32 [frame][H][W].
+In the fp32 storage mode (``PackedWeights(precision="fp32")``, the reference's ``fp32=True``) every activation above is
+fp32 instead of 16-bit; each GEMM operand is split into bf16 [hi | lo | hi] triples right before its product (weights are
+packed [hi | hi | lo]), so the same MFMA kernels accumulate the three-term hi/lo product over K' = 3K.
 torch is used for allocation (caching allocator = workspace reuse) and the stream only.
 """
 import torch
@@ -24,21 +27,37 @@ class Engine:
     def __init__(self, packed):
         self.w = packed
         self.dev = packed.device
-        self.hdt = packed.head_dtype         # 16-bit storage/operand type of the DPT head and the temporal modules
+        self.split = packed.precision == "fp32"
+        self.hdt = packed.head_dtype         # storage/operand type of the DPT head and the temporal modules
+        self.edt = torch.float32 if self.split else BF16      # storage type of the encoder's GEMM operands
 
     # ---- small wrappers -------------------------------------------------------------------------------------------
+    def operand(self, a, relu=False):
+        """The MFMA operand of activation matrix ``a`` [rows, K]: itself, or its bf16 [hi | lo | hi] split in fp32 mode."""
+        if not self.split:
+            return a, relu
+        rows, K = a.shape
+        a3 = _empty((rows, 3 * K), BF16, self.dev)
+        hip.split3(a, a3, rows, K, a.stride(0), K, relu=relu)
+        return a3, False
+
     def linear(self, a, w, out, bias=None, **kw):
+        a, _ = self.operand(a)
         M, K = a.shape[0], a.shape[-1]
-        N = w.shape[0]
-        hip.gemm(a, w, out, M=M, N=N, K=K, lda=a.stride(0), ldc=out.stride(0), bias=bias, **kw)
+        N = kw.pop("N", w.shape[0])
+        hip.gemm(a, w, out, M=M, N=N, K=K, lda=a.stride(0), ldc=kw.pop("ldc", out.stride(0)), bias=bias, **kw)
         return out
 
-    def conv3(self, x, w, bias, cout, stride=1, **kw):
-        """x: bf16 [frames, h, w, cin] -> bf16 [frames, oh, ow, cout]."""
+    def conv3(self, x, w, bias, cout, stride=1, relu_in=False, out=None, ldc=None, **kw):
+        """x: [frames, h, w, cin] -> [frames, oh, ow, cout] (3x3, padding 1), both of the head's storage type."""
         f, h, wd, cin = x.shape
         oh, ow = (h - 1) // stride + 1, (wd - 1) // stride + 1
-        out = _empty((f, oh, ow, cout), self.hdt, self.dev)
-        hip.gemm(x, w, out, M=f * oh * ow, N=cout, K=9 * cin, lda=0, ldc=cout, bias=bias, conv=(h, wd, cin, oh, ow, stride), **kw)
+        if out is None:
+            out = _empty((f, oh, ow, cout), self.hdt, self.dev)
+        a, relu_in = self.operand(x.reshape(f * h * wd, cin), relu_in)
+        cin = a.shape[1]
+        hip.gemm(a, w, out, M=f * oh * ow, N=cout, K=9 * cin, lda=0, ldc=cout if ldc is None else ldc, bias=bias,
+                 relu_in=relu_in, conv=(h, wd, cin, oh, ow, stride), **kw)
         return out
 
     def resize(self, x, oh, ow):
@@ -56,17 +75,17 @@ class Engine:
         hp, wp = H // 14, W // 14
         hw, N = hp * wp, hp * wp + 1
         M = frames * N
-        cols = _empty((frames * hw, 640), BF16, dev)
+        cols = _empty((frames * hw, 640), self.edt, dev)
         hip.im2col_patch14(x, cols, frames, H, W, 640)
         tok = _empty((frames * hw, D), torch.float32, dev)
         self.linear(cols, w.patch_w, tok, w.patch_b)
         xs = _empty((M, D), torch.float32, dev)
         hip.assemble_tokens(tok, w.cls, w.pos_table(hp, wp), xs, frames, hw, D)
         del cols, tok
-        y = _empty((M, D), BF16, dev)
-        qkv = _empty((M, 3 * D), BF16, dev)
-        att = _empty((M, D), BF16, dev)
-        hid = _empty((M, 4 * D), BF16, dev)
+        y = _empty((M, D), self.edt, dev)
+        qkv = _empty((M, 3 * D), self.edt, dev)
+        att = _empty((M, D), self.edt, dev)
+        hid = _empty((M, 4 * D), self.edt, dev)
         taps = []
         for i, b in enumerate(w.blocks):
             hip.layernorm(xs, y, b["ln1_w"], b["ln1_b"], M, D, 1e-6)
@@ -138,11 +157,9 @@ class Engine:
             self.linear(taps[i], w.proj_w[i], p, w.proj_b[i])
             proj.append(p)
         l1 = _empty((frames, 4 * hp, 4 * wp, w.ocp[0]), self.hdt, dev)
-        hip.gemm(proj[0], w.rs0_w, l1, M=frames * hw, N=16 * w.ocp[0], K=w.ocp[0], lda=w.ocp[0], ldc=w.ocp[0], bias=w.rs0_b,
-                 epi=hip.EPI_CONVT, convt=(hp, wp, 4, w.ocp[0]))
+        self.linear(proj[0], w.rs0_w, l1, w.rs0_b, N=16 * w.ocp[0], ldc=w.ocp[0], epi=hip.EPI_CONVT, convt=(hp, wp, 4, w.ocp[0]))
         l2 = _empty((frames, 2 * hp, 2 * wp, w.ocp[1]), self.hdt, dev)
-        hip.gemm(proj[1], w.rs1_w, l2, M=frames * hw, N=4 * w.ocp[1], K=w.ocp[1], lda=w.ocp[1], ldc=w.ocp[1], bias=w.rs1_b,
-                 epi=hip.EPI_CONVT, convt=(hp, wp, 2, w.ocp[1]))
+        self.linear(proj[1], w.rs1_w, l2, w.rs1_b, N=4 * w.ocp[1], ldc=w.ocp[1], epi=hip.EPI_CONVT, convt=(hp, wp, 2, w.ocp[1]))
         l3 = proj[2].reshape(frames, hp, wp, w.ocp[2])
         l4 = self.conv3(proj[3].reshape(frames, hp, wp, w.ocp[3]), w.rs3_w, w.rs3_b, w.ocp[3], stride=2)
         l3 = self.motion(0, l3, B, T)
@@ -160,8 +177,7 @@ class Engine:
         o1 = self.conv3(p1, w.oc1_w, w.oc1_b, w.F2p)
         o1 = self.resize(o1, 14 * hp, 14 * wp)
         depth = _empty((frames, 14 * hp, 14 * wp), torch.float32, dev)
-        hip.gemm(o1, w.oc2_w, depth, M=frames * 196 * hw, N=32, K=9 * w.F2p, lda=0, ldc=4, bias=w.oc2_b, epi=hip.EPI_DOT,
-                 dot_w=w.dot_w, dot_b=w.dot_b, conv=(14 * hp, 14 * wp, w.F2p, 14 * hp, 14 * wp, 1))
+        self.conv3(o1, w.oc2_w, w.oc2_b, 32, out=depth, ldc=4, epi=hip.EPI_DOT, dot_w=w.dot_w, dot_b=w.dot_b)
         return depth
 
     def forward(self, x):

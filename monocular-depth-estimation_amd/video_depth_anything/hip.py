@@ -21,7 +21,7 @@ GROUPNORM_MAX_SPLITS = 64        # VDA_GROUPNORM_MAX_SPLITS: sizes the scratch o
 EXPORTS = [
     "vda_version", "vda_gemm", "vda_attention", "vda_layernorm", "vda_groupnorm", "vda_bilinear_nhwc", "vda_bilinear_f32",
     "vda_im2col_patch14", "vda_assemble_tokens", "vda_temporal_attention", "vda_scale_shift_sums", "vda_solve_scale_shift",
-    "vda_affine_blend", "vda_preprocess_u8",
+    "vda_affine_blend", "vda_preprocess_u8", "vda_split3",
 ]
 
 
@@ -51,14 +51,15 @@ def lib():
         l = C.CDLL(LIB_PATH)
         l.vda_version.restype = C.c_char_p
         l.vda_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
-        l.vda_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.vda_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.vda_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
                                     C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.vda_groupnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_float, C.c_int, C.c_void_p]
         l.vda_bilinear_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
         l.vda_bilinear_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
-        l.vda_im2col_patch14.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.vda_im2col_patch14.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.vda_split3.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.vda_assemble_tokens.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]
         l.vda_temporal_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                              C.c_int, C.c_void_p]
@@ -125,8 +126,10 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
     g.M, g.N, g.K, g.lda, g.ldc, g.ldr, g.ldr2 = M, N, K, lda, ldc, ldr, ldr2
     g.act, g.epi, g.relu_in = act, epi, int(bool(relu_in))
     g.tile_cfg = TILE_CFG if tile_cfg is None else tile_cfg
-    if a.dtype != w.dtype or (resid2 is not None and resid2.dtype != a.dtype):
-        raise TypeError("vda_gemm: a, w and resid2 must share one 16-bit type")
+    if a.dtype != w.dtype:
+        raise TypeError("vda_gemm: a and w must share one 16-bit type")
+    if resid2 is not None and (resid is None or resid2.dtype != resid.dtype):
+        raise TypeError("vda_gemm: resid2 needs resid, of the same type")
     g.ab_type = _type(a)
     g.out_type = _type(out)
     g.resid_type = T_NONE if resid is None else _type(resid)
@@ -179,7 +182,15 @@ def disable_gemm_timing():
 
 def attention(qkv, out, frames, n_tok, heads):
     _dev(qkv, out)
-    _check(lib().vda_attention(_ptr(qkv), _ptr(out), frames, n_tok, heads, _stream()), "vda_attention")
+    if qkv.dtype != out.dtype:
+        raise TypeError("vda_attention: qkv and out must share one type")
+    _check(lib().vda_attention(_ptr(qkv), _ptr(out), frames, n_tok, heads, _type(qkv), _stream()), "vda_attention")
+
+
+def split3(x, out, rows, Cdim, ldx, Cp, relu=False):
+    """fp32 [rows][ldx] -> bf16 [rows][3*Cp] segments [hi | lo | hi] (the A operand of the fp32 mode's GEMMs)."""
+    _dev(x, out)
+    _check(lib().vda_split3(_ptr(x), _ptr(out), rows, Cdim, ldx, Cp, int(bool(relu)), _stream()), "vda_split3")
 
 
 def layernorm(x, out, weight, bias, rows, Cdim, eps, rows_per_group=None, in_group=None, in_skip=0, pe=None, pe_hw=1, pe_T=1):
@@ -209,7 +220,7 @@ def bilinear_f32(x, out, frames, in_h, in_w, out_h, out_w, relu=False):
 
 def im2col_patch14(x, out, frames, H, W, ldk):
     _dev(x, out)
-    _check(lib().vda_im2col_patch14(_ptr(x), _ptr(out), frames, H, W, ldk, _stream()), "vda_im2col_patch14")
+    _check(lib().vda_im2col_patch14(_ptr(x), _ptr(out), frames, H, W, ldk, _type(out), _stream()), "vda_im2col_patch14")
 
 
 def assemble_tokens(tok, cls, pos, x, frames, hw, D):

@@ -64,12 +64,22 @@ def resample_pos_embed(pos_embed, hp, wp):
     return np.concatenate([pe[:1], out.reshape(hp * wp, -1).astype(np.float32)], axis=0)
 
 
-class PackedWeights:
-    """Device-resident kernel-layout weights of one model."""
+def split_weight(w):
+    """fp32 [..., K] -> bf16 [..., 3K] laid out [hi | hi | lo] along the last axis: the weight side of the fp32 mode's
+    three-term product (the activation side is [hi | lo | hi], see vda_split3)."""
+    hi = w.to(BF16)
+    lo = (w - hi.float()).to(BF16)
+    return torch.cat([hi, hi, lo], dim=-1).contiguous()
 
-    def __init__(self, sd, encoder, features, out_channels, device, head_dtype=torch.float16):
+
+class PackedWeights:
+    """Device-resident kernel-layout weights of one model.  ``precision`` "fp32" packs every matrix as bf16 hi/lo triples
+    for the fp32 storage mode (``head_dtype`` is then ignored)."""
+
+    def __init__(self, sd, encoder, features, out_channels, device, head_dtype=torch.float16, precision="half"):
         self.device = device
-        self.head_dtype = head_dtype
+        self.precision = precision
+        self.head_dtype = torch.float32 if precision == "fp32" else head_dtype
         self.encoder = encoder
         D, depth, heads, taps = ENCODERS[encoder]
         self.D, self.depth, self.heads, self.taps = D, depth, heads, taps
@@ -81,8 +91,11 @@ class PackedWeights:
         self._pos_cache = {}
         g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32)  # noqa: E731
         f32 = lambda t: t.contiguous()  # noqa: E731
-        bf = lambda t: t.to(BF16).contiguous()  # noqa: E731
-        hd_ = lambda t: t.to(head_dtype).contiguous()  # noqa: E731
+        if precision == "fp32":
+            bf = hd_ = split_weight
+        else:
+            bf = lambda t: t.to(BF16).contiguous()  # noqa: E731
+            hd_ = lambda t: t.to(head_dtype).contiguous()  # noqa: E731
 
         def padded(t, rows, cols):
             out = torch.zeros((rows, cols), dtype=torch.float32, device=device)
@@ -98,7 +111,7 @@ class PackedWeights:
             w = g(key)                                       # [Cout, Cin, 3, 3]
             out = torch.zeros((cout_p, 9, cin_p), dtype=torch.float32, device=device)
             out[:w.shape[0], :, :w.shape[1]] = w.permute(0, 2, 3, 1).reshape(w.shape[0], 9, w.shape[1])
-            return hd_(out.reshape(cout_p, 9 * cin_p))
+            return hd_(out).reshape(cout_p, -1)              # the hi/lo split, if any, is per filter tap
 
         def convt(key, k, cp):
             w = g(key)                                       # [Cin, Cout, k, k]

@@ -55,6 +55,10 @@ class VideoDepthAnything(nn.Module):
         # rate as bf16 and 3 more mantissa bits; with bf16 here the depth error is 1.6e-2 max-relative (above the 1e-2
         # bound), with fp16 it is set by the bf16 encoder alone.  The reference's own GPU default is fp16 autocast.
         self.head_dtype = torch.float16
+        # "half": 16-bit activations (bf16 encoder, head_dtype head).  "fp32": fp32 activations and three-term bf16 hi/lo
+        # products on the same matrix cores (about 2^-16 per product) -- what ``infer_video_depth(fp32=True)`` selects,
+        # the counterpart of the reference running without autocast (video_depth.py:136).
+        self.precision = "half"
         gen = torch.Generator().manual_seed(0)
         for key, (shape, kind) in state_dict_spec(encoder, features, self.out_channels, num_frames).items():
             if kind in ("nw",):
@@ -69,9 +73,7 @@ class VideoDepthAnything(nn.Module):
             else:
                 t = torch.empty(shape).normal_(0.0, 0.02, generator=gen)
             _install(self, key, t, buffer=(kind == "pe"))
-        self._packed = None
-        self._packed_key = None
-        self._engine = None
+        self._engines = {}            # precision -> (weights key, Engine)
 
     # ---- weights -> kernel layouts, rebuilt whenever the parameters change or move -----------------------------------
     def _weights_key(self):
@@ -83,12 +85,16 @@ class VideoDepthAnything(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("VideoDepthAnything (MI355X build) has no CPU path: call .to('cuda') on a ROCm device first")
         hip.lib()
+        if self.precision not in ("half", "fp32"):
+            raise ValueError(f"precision {self.precision!r}: expected 'half' or 'fp32'")
         key = self._weights_key()
-        if self._engine is None or key != self._packed_key:
-            self._packed = PackedWeights(self.state_dict(), self.encoder, self.features, self.out_channels, dev, self.head_dtype)
-            self._engine = Engine(self._packed)
-            self._packed_key = key
-        return self._engine
+        cached = self._engines.get(self.precision)
+        if cached is None or cached[0] != key:
+            packed = PackedWeights(self.state_dict(), self.encoder, self.features, self.out_channels, dev, self.head_dtype,
+                                   precision=self.precision)
+            cached = (key, Engine(packed))
+            self._engines[self.precision] = cached
+        return cached[1]
 
     @torch.no_grad()
     def forward(self, x):
@@ -114,8 +120,14 @@ class VideoDepthAnything(nn.Module):
         ``frames``: uint8 RGB ``[N, H0, W0, 3]`` array or a list of ``[H0, W0, 3]`` frames.  Returns
         ``(float32 [N, H0, W0], target_fps)``.  Windows of ``min(32, batch_size)`` frames with key-frame carry-over;
         with ``batch_size >= 32`` consecutive windows are affinely aligned and cross-faded, otherwise they are
-        concatenated unaligned exactly like the reference does.  ``fp32`` and ``use_cpu_offload`` are accepted for
-        signature compatibility: arithmetic is always bf16 MFMA with fp32 accumulation, and weights stay in HBM.
+        concatenated unaligned exactly like the reference does.  ``fp32=True`` runs the windows in the fp32 storage mode
+        (see ``precision``); ``use_cpu_offload`` is accepted for signature compatibility (weights stay in HBM).
         """
         from .pipeline import run_video
-        return run_video(self, frames, target_fps, input_size=input_size, device=device, batch_size=batch_size)
+        saved = self.precision
+        if fp32:
+            self.precision = "fp32"
+        try:
+            return run_video(self, frames, target_fps, input_size=input_size, device=device, batch_size=batch_size)
+        finally:
+            self.precision = saved

@@ -37,6 +37,9 @@ def close(got, want, rtol, name=""):
 
 BF_OUT = 6e-3      # bf16 output rounding (2^-8 worst case incl. accumulation noise)
 F32_OUT = 2e-5
+STORAGE = HALVES + [torch.float32]          # activation storage types: 16-bit modes and the fp32 mode
+OUT_TOL = {torch.bfloat16: BF_OUT, torch.float16: BF_OUT, torch.float32: F32_OUT}
+SPLIT_TOL = 6e-5   # three-term bf16 hi/lo product: 2^-16 per operand pair, relative to the largest output
 
 
 def test_library_loads_and_reports_version():
@@ -171,7 +174,7 @@ def test_attention_sharp_softmax_rescale(n_tok):
 def test_layernorm(rows, C):
     x = rnd((rows, C), 1, 2.0, torch.float32) + 0.5
     w, b = rnd((C,), 2, 1.0, torch.float32), rnd((C,), 3, 1.0, torch.float32)
-    for dt, tol in ((BF, BF_OUT), (torch.float16, 1e-3)):
+    for dt, tol in ((BF, BF_OUT), (torch.float16, 1e-3), (torch.float32, F32_OUT)):
         out = torch.empty((rows, C), dtype=dt, device=DEV)
         hip.layernorm(x, out, w, b, rows, C, 1e-6)
         close(out, F.layer_norm(x, (C,), w, b, 1e-6), tol, "layernorm")
@@ -193,7 +196,7 @@ def test_layernorm_drop_class_token_and_position_table():
     close(out, want.reshape(B * T, hw, C), BF_OUT, "layernorm + pe")
 
 
-@pytest.mark.parametrize("dt", HALVES)
+@pytest.mark.parametrize("dt", STORAGE)
 @pytest.mark.parametrize("frames,hw,C", [(4, 37 * 37, 256), (3, 100, 192), (2, 361, 384), (2, 50, 64)])
 def test_groupnorm(frames, hw, C, dt):
     x = rnd((frames, hw, C), 1, 1.5, dt) + 0.3
@@ -205,10 +208,10 @@ def test_groupnorm(frames, hw, C, dt):
     hip.groupnorm(x, out, w, b, work, frames, hw, C, 32, 1e-6)
     assert torch.equal(first, out)          # no atomics: bit-identical from run to run
     want = F.group_norm(x.float().permute(0, 2, 1), 32, w, b, 1e-6).permute(0, 2, 1)
-    close(out, want, BF_OUT, "groupnorm")
+    close(out, want, OUT_TOL[dt], "groupnorm")
 
 
-@pytest.mark.parametrize("dt", HALVES)
+@pytest.mark.parametrize("dt", STORAGE)
 @pytest.mark.parametrize("ih,iw,oh,ow", [(19, 19, 37, 37), (37, 66, 74, 132), (5, 7, 10, 14), (8, 8, 14, 14), (6, 6, 6, 6)])
 def test_bilinear(ih, iw, oh, ow, dt):
     frames, C = 2, 64
@@ -216,7 +219,7 @@ def test_bilinear(ih, iw, oh, ow, dt):
     out = torch.empty((frames, oh, ow, C), dtype=dt, device=DEV)
     hip.bilinear_nhwc(x, out, frames, ih, iw, oh, ow, C)
     want = F.interpolate(x.float().permute(0, 3, 1, 2), size=(oh, ow), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
-    close(out, want, BF_OUT, "bilinear nhwc")
+    close(out, want, OUT_TOL[dt], "bilinear nhwc")
     xf = rnd((frames, ih, iw), 2, 1.0, torch.float32)
     of = torch.empty((frames, oh, ow), dtype=torch.float32, device=DEV)
     hip.bilinear_f32(xf, of, frames, ih, iw, oh, ow, relu=True)
@@ -230,8 +233,11 @@ def test_patch_embed_front_end():
     wt = rnd((D, 3, 14, 14), 2, 1 / math.sqrt(588))
     bias = rnd((D,), 3, 0.1, torch.float32)
     hp, wp = H // 14, W // 14
+    cols32 = torch.empty((frames * hp * wp, 640), dtype=torch.float32, device=DEV)
+    hip.im2col_patch14(x, cols32, frames, H, W, 640)
     cols = torch.empty((frames * hp * wp, 640), dtype=BF, device=DEV)
     hip.im2col_patch14(x, cols, frames, H, W, 640)
+    assert torch.equal(cols32.to(BF), cols)
     want_cols = F.unfold(x, 14, stride=14).transpose(1, 2).reshape(frames * hp * wp, 588)
     assert torch.equal(cols[:, :588].float(), want_cols.to(BF).float())
     assert torch.count_nonzero(cols[:, 588:]) == 0
@@ -248,7 +254,7 @@ def test_patch_embed_front_end():
     assert torch.equal(xt, want)
 
 
-@pytest.mark.parametrize("dt", HALVES)
+@pytest.mark.parametrize("dt", STORAGE)
 @pytest.mark.parametrize("B,T,hw,heads,hd", [(1, 32, 12, 8, 24), (2, 5, 7, 8, 48), (1, 32, 9, 8, 8), (1, 32, 10, 8, 128), (1, 4, 6, 8, 32), (1, 1, 5, 8, 8)])
 def test_temporal_attention(B, T, hw, heads, hd, dt):
     C = heads * hd
@@ -258,7 +264,7 @@ def test_temporal_attention(B, T, hw, heads, hd, dt):
     q, k, v = qkv.float().reshape(B, T, hw, 3, heads, hd).permute(3, 0, 2, 4, 1, 5)      # [B, hw, heads, T, hd]
     want = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v
     want = want.permute(0, 3, 1, 2, 4).reshape(B * T * hw, C)
-    close(out, want, BF_OUT, "temporal attention")
+    close(out, want, OUT_TOL[dt], "temporal attention")
 
 
 def test_stitch_kernels():
@@ -280,6 +286,66 @@ def test_stitch_kernels():
     assert torch.allclose(out, want, rtol=1e-6, atol=1e-6)
     hip.affine_blend(x, None, out, ss, 0.0, 1.0, n)
     assert torch.allclose(out, torch.clamp(x * ss[0] + ss[1], min=0), rtol=1e-6, atol=1e-6)
+
+
+def split_w(w):
+    from video_depth_anything.packing import split_weight
+    return split_weight(w)
+
+
+@pytest.mark.parametrize("rows,C,Cp,relu", [(1000, 256, 256, False), (37, 48, 64, True), (5, 640, 640, False)])
+def test_split3_layout_and_accuracy(rows, C, Cp, relu):
+    x = rnd((rows, C + 4), 1, 3.0, torch.float32)[:, :C]                  # row stride larger than C
+    out = torch.full((rows, 3 * Cp), float("nan"), dtype=BF, device=DEV)
+    hip.split3(x, out, rows, C, x.stride(0), Cp, relu=relu)
+    ref = F.relu(x) if relu else x
+    hi, lo, hi2 = out[:, :C].float(), out[:, Cp:Cp + C].float(), out[:, 2 * Cp:2 * Cp + C].float()
+    assert torch.equal(hi, ref.to(BF).float()) and torch.equal(hi, hi2)
+    assert torch.equal(lo, (ref - hi).to(BF).float())
+    assert ((hi + lo) - ref).abs().max() <= 2.0 ** -16 * ref.abs().max()
+    for seg in range(3):
+        assert torch.count_nonzero(out[:, seg * Cp + C:(seg + 1) * Cp]) == 0
+
+
+@pytest.mark.parametrize("cfg", TILE_CFGS)
+@pytest.mark.parametrize("M,N,K", [(1370, 1024, 1024), (300, 192, 384)])
+def test_gemm_fp32_mode_three_term_product(M, N, K, cfg):
+    """fp32 operands through vda_split3 / split weights: close to an fp64 product, ~100x closer than one bf16 pass."""
+    a, w = rnd((M, K), 1, 1.0, torch.float32), rnd((N, K), 2, 1 / math.sqrt(K), torch.float32)
+    bias = rnd((N,), 3, 0.1, torch.float32)
+    a3 = torch.empty((M, 3 * K), dtype=BF, device=DEV)
+    hip.split3(a, a3, M, K, K, K)
+    out = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    hip.gemm(a3, split_w(w), out, M=M, N=N, K=3 * K, lda=3 * K, ldc=N, bias=bias, act=hip.ACT_GELU, tile_cfg=cfg)
+    want = F.gelu(a.double() @ w.double().t() + bias.double()).float()
+    close(out, want, SPLIT_TOL, "three-term gemm")
+
+
+def test_conv3x3_fp32_mode():
+    B, h, w_, cin, cout = 2, 19, 13, 64, 128
+    x = rnd((B, cin, h, w_), 1, 1.0, torch.float32)
+    wt = rnd((cout, cin, 3, 3), 2, 1 / math.sqrt(9 * cin), torch.float32)
+    bias = rnd((cout,), 3, 0.1, torch.float32)
+    want = F.conv2d(F.relu(x).double(), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1).float()
+    a = x.permute(0, 2, 3, 1).contiguous().reshape(B * h * w_, cin)
+    a3 = torch.empty((B * h * w_, 3 * cin), dtype=BF, device=DEV)
+    hip.split3(a, a3, B * h * w_, cin, cin, cin, relu=True)
+    wg = split_w(wt.permute(0, 2, 3, 1).contiguous()).reshape(cout, 27 * cin)
+    out = torch.empty((B, h, w_, cout), dtype=torch.float32, device=DEV)
+    hip.gemm(a3, wg, out, M=B * h * w_, N=cout, K=27 * cin, lda=0, ldc=cout, bias=bias, conv=(h, w_, 3 * cin, h, w_, 1))
+    close(out, want, SPLIT_TOL, "three-term conv3x3")
+
+
+@pytest.mark.parametrize("frames,n_tok,heads", [(2, 1370, 2), (1, 129, 3), (2, 36, 1)])
+def test_attention_fp32_mode(frames, n_tok, heads):
+    D = heads * 64
+    qkv = rnd((frames, n_tok, 3 * D), 1, 1.0, torch.float32)
+    qkv[..., :D] *= 0.35
+    out = torch.full((frames, n_tok, D), float("nan"), dtype=torch.float32, device=DEV)
+    hip.attention(qkv, out, frames, n_tok, heads)
+    q, k, v = qkv.double().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    want = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(frames, n_tok, D).float()
+    close(out, want, 2e-4, "attention, fp32 mode")
 
 
 def test_rejected_arguments_return_error_codes():
