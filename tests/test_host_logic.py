@@ -94,8 +94,9 @@ def test_shared_library_exports_every_declared_symbol():
 # ---- stand-ins for the device entry points used by the host pipeline ------------------------------------------------
 def _standins(monkeypatch):
     def preprocess_u8(u8, out, frames, h0, w0, H, W):
-        assert (h0, w0) == (H, W)
-        out.copy_(torch.from_numpy(O.normalize_frame(u8.numpy())))
+        assert (h0, w0) == (H, W) and u8.shape == (frames, h0, w0, 3)
+        for i in range(frames):
+            out[i].copy_(torch.from_numpy(O.normalize_frame(u8[i].numpy())))
 
     def bilinear_f32(x, out, frames, ih, iw, oh, ow, relu=False):
         out.copy_(F.interpolate(x.reshape(frames, 1, ih, iw), size=(oh, ow), mode="bilinear", align_corners=True).reshape(frames, oh, ow))
