@@ -46,15 +46,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a single device: every rank uses cuda:0 and the gloo backend")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse_on_one_gpu:
+        local = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
@@ -123,7 +130,7 @@ def main():
                 out["roofline"].update(pmc_traffic("gemm256_kernelILi0ELb0EDF16b"))
         if not args.no_end_to_end and world == 1:
             out["end_to_end"] = end_to_end(model, H, W)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.encoder, H, W)
         print(json.dumps(out), flush=True)
     if world > 1:
