@@ -81,9 +81,9 @@ typedef struct VdaGemmArgs {
     int relu_in;          /* apply ReLU to A while loading (pre-activation conv, util/blocks.py:78) */
     int in_h, in_w, cin, out_h, out_w, stride;   /* CONV3 geometry; cin % 64 == 0, M = imgs*out_h*out_w */
     int ct_h, ct_w, ct_k, ct_c;                  /* EPI_CONVT geometry                                   */
-    int tile_cfg;         /* 0 = the library picks the workgroup tile; 1 or 2 force one where the shape allows it (tuning
-                             and tests): 1 = 128x128 / 4 waves, 2 = 256x256 / 8 waves, 4-phase pipelined; other values
-                             are VDA_EINVAL */
+    int tile_cfg;         /* 0 = the library picks the kernel; 1..3 force one where the call allows it (tuning and tests):
+                             1 = 128x128 tile / 4 waves, 2 = 256x256 tile / 8 waves, 4-phase pipelined, 3 = direct 3x3
+                             convolution (stride 1, N = 32 / 64 / 128, no residual); other values are VDA_EINVAL */
 } VdaGemmArgs;
 
 int vda_gemm(const VdaGemmArgs* args, void* stream);

@@ -185,8 +185,13 @@ extern "C" int vda_gemm(const VdaGemmArgs* args, void* stream) {
     }
     if (a.out_type != VDA_T_F32 && a.out_type != VDA_T_BF16 && a.out_type != VDA_T_F16) return VDA_EINVAL;
     if (a.ab_type != VDA_T_BF16 && a.ab_type != VDA_T_F16) return VDA_EINVAL;
-    if (a.tile_cfg < 0 || a.tile_cfg > 2) return VDA_EINVAL;
+    if (a.tile_cfg < 0 || a.tile_cfg > 3) return VDA_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // narrow 3x3 convolutions: the direct kernel copies each input pixel once per patch instead of once per tap
+    if ((a.tile_cfg == 0 || a.tile_cfg == 3) && conv_direct_supports(a)) {
+        const long patches = (long)(a.M / (a.out_h * a.out_w)) * ((a.out_h + 7) / 8) * ((a.out_w + 31) / 32);
+        if (a.tile_cfg == 3 || patches >= 512) return launch_conv_direct(a, s);
+    }
     if (a.N <= 32) return launch<128, 32, 4, 1>(a, s);
     if (a.N <= 64) return launch<128, 64, 2, 2>(a, s);
     // The 256x256 pipelined kernel moves half as many bytes global -> LDS per MFMA as the 128x128 one, which is what bounds

@@ -252,5 +252,7 @@ __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)
 
 // 256x256-tile kernel with the 4-phase software pipeline (gemm256.hip)
 int launch_gemm256(const VdaGemmArgs& a, hipStream_t s);
+bool conv_direct_supports(const VdaGemmArgs& a);              // conv_direct.hip: direct 3x3 convolution, N = 32 / 64 / 128
+int launch_conv_direct(const VdaGemmArgs& a, hipStream_t s);
 
 }  // namespace vda

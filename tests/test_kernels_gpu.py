@@ -20,7 +20,7 @@ BF = torch.bfloat16
 
 HALVES = [torch.bfloat16, torch.float16]
 # workgroup tiles of vda_gemm: library's choice, forced 128x128, forced 256x256 pipelined (small shapes exercise its M/N tails)
-TILE_CFGS = [0, 1, 2]
+TILE_CFGS = [0, 1, 2, 3]      # 3 = direct 3x3 convolution kernel where the call allows it, else the library's choice
 
 
 def rnd(shape, seed, scale=1.0, dtype=BF):
@@ -130,8 +130,9 @@ def test_gemm_conv3x3(stride, cin, cout, relu_in, dt, cfg):
     close(out, want, BF_OUT, "conv3x3")
 
 
-def test_gemm_conv3x3_dot_tail():
-    B, h, w_, cin = 2, 20, 30, 64
+@pytest.mark.parametrize("cfg", [1, 3])
+@pytest.mark.parametrize("B,h,w_,cin", [(2, 20, 30, 64), (1, 37, 70, 128)])
+def test_gemm_conv3x3_dot_tail(B, h, w_, cin, cfg):
     x = rnd((B, cin, h, w_), 1)
     wt = rnd((32, cin, 3, 3), 2, 1 / math.sqrt(9 * cin))
     bias = rnd((32,), 3, 0.3, torch.float32)
@@ -141,8 +142,31 @@ def test_gemm_conv3x3_dot_tail():
     wg = wt.permute(0, 2, 3, 1).reshape(32, 9 * cin).contiguous()
     out = torch.full((B * h * w_,), float("nan"), dtype=torch.float32, device=DEV)
     hip.gemm(a, wg, out, M=B * h * w_, N=32, K=9 * cin, lda=0, ldc=4, bias=bias, epi=hip.EPI_DOT, dot_w=w2, dot_b=0.1,
-             conv=(h, w_, cin, h, w_, 1))
+             conv=(h, w_, cin, h, w_, 1), tile_cfg=cfg)
     close(out.reshape(B, 1, h, w_), want, 1e-4, "conv+dot tail")
+
+
+@pytest.mark.parametrize("out_dt", [torch.float16, torch.float32])
+@pytest.mark.parametrize("B,h,w_,cin,cout,act", [(2, 19, 45, 64, 128, False), (1, 40, 33, 256, 128, True), (3, 8, 32, 128, 64, True),
+                                                 (1, 9, 70, 192, 32, False)])
+def test_conv3x3_direct_kernel_matches_implicit_gemm_and_torch(B, h, w_, cin, cout, act, out_dt):
+    """Patches that are cut by the right and bottom image borders, several 64-channel slices, every supported width."""
+    dt = torch.float16
+    x = rnd((B, cin, h, w_), 1, 1.0, dt)
+    wt = rnd((cout, cin, 3, 3), 2, 1 / math.sqrt(9 * cin), dt)
+    bias = rnd((cout,), 3, 0.1, torch.float32)
+    want = F.conv2d(x.float(), wt.float(), bias, padding=1)
+    want = (F.relu(want) if act else want).permute(0, 2, 3, 1)
+    a = x.permute(0, 2, 3, 1).contiguous()
+    wg = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
+    outs = []
+    for cfg in (1, 3):
+        out = torch.full((B, h, w_, cout), float("nan"), dtype=out_dt, device=DEV)
+        hip.gemm(a, wg, out, M=B * h * w_, N=cout, K=9 * cin, lda=0, ldc=cout, bias=bias, act=hip.ACT_RELU if act else hip.ACT_NONE,
+                 conv=(h, w_, cin, h, w_, 1), tile_cfg=cfg)
+        close(out, want, OUT_TOL[out_dt] if out_dt != torch.float32 else 1e-4, f"conv3x3 cfg {cfg}")
+        outs.append(out)
+    close(outs[1], outs[0], OUT_TOL[out_dt] if out_dt != torch.float32 else 1e-5, "direct vs implicit GEMM")
 
 
 @pytest.mark.parametrize("frames,n_tok,heads", [(2, 1370, 6), (3, 64, 2), (1, 129, 16), (2, 36, 1), (1, 4100, 2), (1, 5477, 1)])
