@@ -83,7 +83,7 @@ typedef struct VdaGemmArgs {
     int ct_h, ct_w, ct_k, ct_c;                  /* EPI_CONVT geometry                                   */
     int tile_cfg;         /* 0 = the library picks the kernel; 1..3 force one where the call allows it (tuning and tests):
                              1 = 128x128 tile / 4 waves, 2 = 256x256 tile / 8 waves, 4-phase pipelined, 3 = direct 3x3
-                             convolution (stride 1, N = 32 / 64 / 128, no residual); other values are VDA_EINVAL */
+                             convolution (stride 1, N = 32, 64 or a multiple of 128, no gamma); other values are VDA_EINVAL */
 } VdaGemmArgs;
 
 int vda_gemm(const VdaGemmArgs* args, void* stream);

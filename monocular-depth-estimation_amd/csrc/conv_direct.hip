@@ -1,4 +1,5 @@
-// Direct 3x3 convolution (padding 1, stride 1) for narrow outputs: N = 32, 64 or 128 output channels.
+// Direct 3x3 convolution (padding 1, stride 1): N = 32, 64 or a multiple of 128 output channels (blocks of 128 channels are
+// separate workgroups, grid.y).
 //
 // As an implicit GEMM a 3x3 convolution gathers every input pixel nine times; with few output channels there is little
 // MFMA work per gathered byte and the global -> LDS copy path, not the matrix pipe, sets the time (128 output channels:
@@ -28,7 +29,7 @@ constexpr int HALO_W = PT_W + 2, HALO_H = PT_H + 2, HALO_PX = HALO_W * HALO_H;
 constexpr int HALO_ITERS = (HALO_PX * 8 + 255) / 256;      // 16-byte pieces per thread and slice
 constexpr int HALO_BYTES = HALO_ITERS * 256 * 16;          // whole iterations: lanes past the last pixel copy zeros into the pad
 
-template <int TN, int TPS, typename T>
+template <int TN, int TPS, bool RELU_IN, typename T>
 __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs p, const int tiles_x, const int tiles_y) {
     typedef typename Vec<T>::v8 frag_t;
     constexpr int N = TN * 16;
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     const int oy0 = ty * PT_H, ox0 = tx * PT_W;
     const bf16* a_img = reinterpret_cast<const bf16*>(p.a) + (size_t)img * p.in_h * p.in_w * p.cin;
     const bf16* zsrc = reinterpret_cast<const bf16*>(p.zeros);
+    const int n0 = blockIdx.y * N;                           // first output channel of this workgroup
 
     // ---- copy sources (element offsets inside the image; -1 = padding or pad lanes: copy zeros) ------------------------------
     int hoff[HALO_ITERS];
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     };
     auto issue_w = [&](int s, int buf) {
         const int cc = s / SPC, tap0 = (s - cc * SPC) * TPS;
-        const bf16* wb = reinterpret_cast<const bf16*>(p.w) + tap0 * p.cin + cc * 64;
+        const bf16* wb = reinterpret_cast<const bf16*>(p.w) + ((size_t)n0 * 9 + tap0) * p.cin + cc * 64;
 #pragma unroll
         for (int it = 0; it < W_ITERS; ++it) glds16(wb + woff[it], wbuf + buf * W_BYTES + (it * 256 + wave * 64) * 16);
     };
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int hp = hbase[i] + toff;
-                    const frag_t af = *reinterpret_cast<const frag_t*>(halo + hp * 128 + (((ks * 4 + fq) ^ (hp & 7)) << 4));
+                    frag_t af = *reinterpret_cast<const frag_t*>(halo + hp * 128 + (((ks * 4 + fq) ^ (hp & 7)) << 4));
+                    if (RELU_IN) af = relu8(af);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(wf[j], af, acc[i][j]);
                 }
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     f32x4 bias[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-        bias[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + j * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bias[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (p.epi == VDA_EPI_DOT) {
         f32x4 dw[TN];
@@ -172,6 +175,9 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     const int c_row = lane / cpr, c_chunk = lane - c_row * cpr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        const int oy = oy0 + 2 * wave + (i >> 1), oxb = ox0 + (i & 1) * 16;
+        const bool mine = oy < p.out_h && oxb + frow < p.out_w;                   // this lane's pixel exists
+        const size_t pix = ((size_t)img * p.out_h + oy) * p.out_w + oxb + frow;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             f32x4 v = acc[i][j] + bias[j];
@@ -179,10 +185,13 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
+            if (mine && p.resid_type != VDA_T_NONE) {
+                v += load4(p.resid, p.resid_type, pix * p.ldr + n0 + j * 16 + fq * 4);
+                if (p.resid2) v += load4(p.resid2, p.resid_type, pix * p.ldr2 + n0 + j * 16 + fq * 4);
+            }
             store4(stage + frow * rs, p.out_type, j * 16 + fq * 4, v);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int oy = oy0 + 2 * wave + (i >> 1), oxb = ox0 + (i & 1) * 16;
         for (int r0 = 0; r0 < 16; r0 += rpi) {
             const int row = r0 + c_row;
             if (row < 16) {
@@ -190,29 +199,34 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
                 const int ox = oxb + row;
                 if (oy < p.out_h && ox < p.out_w)
                     *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.out) +
-                                              (((size_t)img * p.out_h + oy) * p.out_w + ox) * p.ldc * esz + (c_chunk << 4)) = v;
+                                              ((((size_t)img * p.out_h + oy) * p.out_w + ox) * p.ldc + n0) * esz + (c_chunk << 4)) = v;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
-template <int TN, int TPS, typename T>
+template <int TN, int TPS, bool RELU_IN, typename T>
 int launch_cfg(const VdaGemmArgs& a, hipStream_t s) {
     const int tiles_x = (a.out_w + PT_W - 1) / PT_W, tiles_y = (a.out_h + PT_H - 1) / PT_H;
     const int imgs = a.M / (a.out_h * a.out_w);
     const int lds = HALO_BYTES + 2 * TPS * TN * 16 * 128;
-    auto k = conv3_direct_kernel<TN, TPS, T>;
+    auto k = conv3_direct_kernel<TN, TPS, RELU_IN, T>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)(imgs * tiles_x * tiles_y)), dim3(256), lds, s, a, tiles_x, tiles_y);
+    hipLaunchKernelGGL(k, dim3((unsigned)(imgs * tiles_x * tiles_y), a.N / (TN * 16)), dim3(256), lds, s, a, tiles_x, tiles_y);
     return hip_rc(hipGetLastError());
+}
+
+template <bool RELU_IN, typename T>
+int launch_r(const VdaGemmArgs& a, hipStream_t s) {
+    if (a.N % 128 == 0) return launch_cfg<8, 1, RELU_IN, T>(a, s);
+    if (a.N == 64) return launch_cfg<4, 3, RELU_IN, T>(a, s);
+    return launch_cfg<2, 3, RELU_IN, T>(a, s);
 }
 
 template <typename T>
 int launch_t(const VdaGemmArgs& a, hipStream_t s) {
-    if (a.N == 128) return launch_cfg<8, 1, T>(a, s);
-    if (a.N == 64) return launch_cfg<4, 3, T>(a, s);
-    return launch_cfg<2, 3, T>(a, s);
+    return a.relu_in ? launch_r<true, T>(a, s) : launch_r<false, T>(a, s);
 }
 
 }  // namespace
@@ -220,8 +234,8 @@ int launch_t(const VdaGemmArgs& a, hipStream_t s) {
 // true if the direct kernel implements this call (the caller has validated the arguments of vda_gemm)
 bool conv_direct_supports(const VdaGemmArgs& a) {
     if (a.a_mode != VDA_A_CONV3 || a.stride != 1 || a.out_h != a.in_h || a.out_w != a.in_w) return false;
-    if (a.N != 32 && a.N != 64 && a.N != 128) return false;
-    if (a.relu_in || a.gamma || a.resid_type != VDA_T_NONE || a.resid2) return false;
+    if (a.N != 32 && a.N != 64 && a.N % 128 != 0) return false;
+    if (a.gamma) return false;
     if (a.epi == VDA_EPI_DOT) return a.N == 32;
     if (a.epi != VDA_EPI_PLAIN || a.act == VDA_ACT_GELU) return false;
     const int esz = a.out_type == VDA_T_F32 ? 4 : 2;

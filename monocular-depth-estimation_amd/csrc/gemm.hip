@@ -187,10 +187,14 @@ extern "C" int vda_gemm(const VdaGemmArgs* args, void* stream) {
     if (a.ab_type != VDA_T_BF16 && a.ab_type != VDA_T_F16) return VDA_EINVAL;
     if (a.tile_cfg < 0 || a.tile_cfg > 3) return VDA_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // narrow 3x3 convolutions: the direct kernel copies each input pixel once per patch instead of once per tap
+    // 3x3 convolutions: the direct kernel copies each input pixel once per patch and channel slice instead of once per tap.
+    // Narrow outputs (N <= 128) always gain (1.3x at N = 128, 1.8x at N = 32); wide ones only while the 8 x 32 patches
+    // cover the image well (148 x 148: 90 % covered, +10 %; 74 x 74: 71 %, -4 % against the 256x256 tile).
     if ((a.tile_cfg == 0 || a.tile_cfg == 3) && conv_direct_supports(a)) {
-        const long patches = (long)(a.M / (a.out_h * a.out_w)) * ((a.out_h + 7) / 8) * ((a.out_w + 31) / 32);
-        if (a.tile_cfg == 3 || patches >= 512) return launch_conv_direct(a, s);
+        const long ty = (a.out_h + 7) / 8, tx = (a.out_w + 31) / 32;
+        const long patches = (long)(a.M / (a.out_h * a.out_w)) * ty * tx;
+        const bool covered = (long)a.out_h * a.out_w * 100 >= ty * 8 * tx * 32 * 88;
+        if (a.tile_cfg == 3 || (patches >= 512 && (a.N <= 128 || covered))) return launch_conv_direct(a, s);
     }
     if (a.N <= 32) return launch<128, 32, 4, 1>(a, s);
     if (a.N <= 64) return launch<128, 64, 2, 2>(a, s);

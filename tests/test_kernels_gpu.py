@@ -169,6 +169,25 @@ def test_conv3x3_direct_kernel_matches_implicit_gemm_and_torch(B, h, w_, cin, co
     close(outs[1], outs[0], OUT_TOL[out_dt] if out_dt != torch.float32 else 1e-5, "direct vs implicit GEMM")
 
 
+@pytest.mark.parametrize("B,h,w_,C", [(2, 19, 45, 256), (1, 40, 33, 128)])
+def test_conv3x3_direct_kernel_residual_unit(B, h, w_, C):
+    """The second convolution of a residual unit: ReLU on the input, two residual maps added (util/blocks.py:78-91, 147-152)."""
+    dt = torch.float16
+    x, r1, r2 = rnd((B, h, w_, C), 1, 1.0, dt), rnd((B, h, w_, C), 4, 1.0, dt), rnd((B, h, w_, C), 5, 1.0, dt)
+    wt = rnd((C, C, 3, 3), 2, 1 / math.sqrt(9 * C), dt)
+    bias = rnd((C,), 3, 0.1, torch.float32)
+    want = F.conv2d(F.relu(x.float().permute(0, 3, 1, 2)), wt.float(), bias, padding=1).permute(0, 2, 3, 1) + r1.float() + r2.float()
+    wg = wt.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()
+    outs = []
+    for cfg in (1, 3):
+        out = torch.full((B, h, w_, C), float("nan"), dtype=dt, device=DEV)
+        hip.gemm(x, wg, out, M=B * h * w_, N=C, K=9 * C, lda=0, ldc=C, bias=bias, relu_in=True, resid=r1.reshape(-1, C), ldr=C,
+                 resid2=r2.reshape(-1, C), ldr2=C, conv=(h, w_, C, h, w_, 1), tile_cfg=cfg)
+        close(out, want, BF_OUT, f"residual unit conv cfg {cfg}")
+        outs.append(out)
+    close(outs[1], outs[0], 1e-3, "direct vs implicit GEMM")      # same products; the fp32 accumulation order differs
+
+
 @pytest.mark.parametrize("frames,n_tok,heads", [(2, 1370, 6), (3, 64, 2), (1, 129, 16), (2, 36, 1), (1, 4100, 2), (1, 5477, 1)])
 def test_attention(frames, n_tok, heads):
     D = heads * 64
