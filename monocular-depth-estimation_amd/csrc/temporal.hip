@@ -5,6 +5,7 @@
 // a half reads the same address), the two halves are combined with one lane ^ 32 exchange per key, the softmax over the
 // T scores is lane-local, and the lane then accumulates its half of the output row.  The arithmetic is tiny (T*T*hd per
 // wave); the kernel is bound by the strided gather of the T rows, which it reads exactly once.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -25,10 +26,28 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const T16* __restrict
     const size_t fstride = (size_t)hw * ld;                       // distance between consecutive frames of one position
     const T16* base = qkv + ((size_t)b * T * hw + p) * ld + head * HD;
 
-    for (int idx = lane; idx < T * (HD / 4); idx += 64) {
-        const int j = idx / (HD / 4), c = (idx - j * (HD / 4)) * 4;
-        *reinterpret_cast<v4_t*>(&ks[j * HD + c]) = *reinterpret_cast<const v4_t*>(base + j * fstride + C + c);
-        *reinterpret_cast<v4_t*>(&vs[j * HD + c]) = *reinterpret_cast<const v4_t*>(base + j * fstride + 2 * C + c);
+    // K and V rows of the T frames: 16-byte pieces (8 values of a 16-bit type, 4 of fp32), all loads of a lane issued
+    // before the first LDS store so that they are in flight together
+    constexpr int PV = 16 / sizeof(T16);                            // values per 16-byte piece
+    typedef typename std::conditional<sizeof(T16) == 2, typename Vec<T16>::v8, typename Vec<T16>::v4>::type piece_t;
+    constexpr int PPR = HD / PV;                                    // pieces per row
+    constexpr int NIT = (32 * PPR + 63) / 64;
+    piece_t kp[NIT], vp[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 64 + lane;
+        const int j = min(idx / PPR, T - 1), c = (idx % PPR) * PV;
+        kp[it] = *reinterpret_cast<const piece_t*>(base + j * fstride + C + c);
+        vp[it] = *reinterpret_cast<const piece_t*>(base + j * fstride + 2 * C + c);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 64 + lane;
+        const int j = idx / PPR, c = (idx % PPR) * PV;
+        if (j < T) {
+            *reinterpret_cast<piece_t*>(&ks[j * HD + c]) = kp[it];
+            *reinterpret_cast<piece_t*>(&vs[j * HD + c]) = vp[it];
+        }
     }
     float q[HH];
     {
