@@ -1,4 +1,4 @@
-"""Throughput of the per-window forward pass (the metric of BASELINE.json) on N MI355X GPUs of one node.
+"""Throughput of the per-window forward pass (frames per second, 32-frame windows at 518 px) on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
