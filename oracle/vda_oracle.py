@@ -8,8 +8,9 @@ It is a functional, fp32, plain-torch/numpy restatement of the reference algorit
 ``state_dict`` (no nn.Module tree).  Each function cites the reference lines it follows.  It is pinned to the
 reference by the golden vectors under ``tests/golden/`` which ``oracle/make_goldens.py`` produced by importing
 the unmodified reference model in the build container (the reference's own tests hold no fixtures for this
-path).  The OpenCV bicubic image resize of the preprocessing step is NOT covered (cv2 is absent everywhere this
-runs): frames are fed at network size, and that one step is "parity unpinned".
+path).  The OpenCV bicubic image resize of the preprocessing step cannot be pinned that way (cv2 is absent everywhere
+this runs): ``cv_resize_cubic`` restates OpenCV's published INTER_CUBIC arithmetic and that one step is "parity
+unpinned"; the golden vectors feed frames at network size.
 """
 import math
 
@@ -262,6 +263,52 @@ def normalize_frame(frame_u8):
     return np.ascontiguousarray(np.transpose(img, (2, 0, 1))).astype(np.float32)
 
 
+def cv_resize_cubic(img, out_h, out_w):
+    """float32 HWC image -> (out_h, out_w) with the arithmetic OpenCV documents for ``cv2.resize(..., INTER_CUBIC)`` on
+    float images, which is what the reference calls (util/transform.py:109-125 via video_depth.py:80-92): source
+    coordinate (dst + 0.5) * in/out - 0.5, the four Keys taps with A = -0.75 (the fourth weight is 1 minus the other
+    three), source indices clamped to the border, horizontal pass then vertical pass in float32.
+    PARITY UNPINNED: cv2 is absent here and on the GPU box and the reference holds no resized fixture, so this restates
+    the published algorithm instead of checking against OpenCV itself."""
+    img = np.asarray(img, dtype=np.float32)
+    in_h, in_w = img.shape[:2]
+
+    def taps(n_in, n_out):
+        scale = float(n_in) / float(n_out)
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        A = np.float32(-0.75)
+        one = np.float32(1.0)
+        w0 = ((A * (f + one) - np.float32(5.0) * A) * (f + one) + np.float32(8.0) * A) * (f + one) - np.float32(4.0) * A
+        w1 = ((A + np.float32(2.0)) * f - (A + np.float32(3.0))) * f * f + one
+        g = one - f
+        w2 = ((A + np.float32(2.0)) * g - (A + np.float32(3.0))) * g * g + one
+        w3 = one - w0 - w1 - w2
+        idx = np.clip(s[:, None] + np.arange(-1, 3)[None, :], 0, n_in - 1)
+        return idx, np.stack([w0, w1, w2, w3], 1).astype(np.float32)
+
+    ix, wx = taps(in_w, out_w)
+    iy, wy = taps(in_h, out_h)
+    rows = np.zeros((in_h, out_w) + img.shape[2:], dtype=np.float32)
+    for k in range(4):                                   # horizontal pass, taps added in order
+        rows = rows + wx[:, k].reshape((1, out_w) + (1,) * (img.ndim - 2)) * img[:, ix[:, k]]
+    out = np.zeros((out_h, out_w) + img.shape[2:], dtype=np.float32)
+    for k in range(4):
+        out = out + wy[:, k].reshape((out_h, 1) + (1,) * (img.ndim - 2)) * rows[iy[:, k]]
+    return out.astype(np.float32)
+
+
+def preprocess_frame(frame_u8, H, W):
+    """uint8 HWC frame of any size -> float32 CHW at network size (H, W): /255, bicubic resize, ImageNet normalisation
+    (reference: video_depth.py:80-92,120; util/transform.py:109-158)."""
+    img = frame_u8.astype(np.float32) / np.float32(255.0)
+    if img.shape[:2] != (H, W):
+        img = cv_resize_cubic(img, H, W)
+    img = (img - [0.485, 0.456, 0.406]) / [0.229, 0.224, 0.225]
+    return np.ascontiguousarray(np.transpose(img, (2, 0, 1))).astype(np.float32)
+
+
 def scale_shift(pred, target):
     """Closed-form least squares ``target ~ s*pred + t`` with an all-ones mask, in float32
     (reference: utils/util.py:40-62)."""
@@ -339,16 +386,18 @@ def stitch(depth_list, n_frames, batch_size=32):
 
 
 @torch.no_grad()
-def infer_video_depth(sd, frames, encoder, batch_size=32, forward_fn=None):
-    """Whole-video inference on frames that are already at network size (reference: video_depth.py:67-209).
-    Returns float32 ``[N, H, W]``."""
+def infer_video_depth(sd, frames, encoder, batch_size=32, forward_fn=None, input_size=None):
+    """Whole-video inference (reference: video_depth.py:67-209).  With ``input_size`` None the frames must already be at
+    network size; otherwise they are resized to ``network_size(h0, w0, input_size)`` first and the depth is resampled
+    back to the frame size.  Returns float32 ``[N, h0, w0]``."""
     n = len(frames)
     H, W = frames[0].shape[:2]
+    Hn, Wn = (H, W) if input_size is None else network_size(H, W, input_size)
     plan, L, O, _ = window_plan(n, batch_size)
     fwd = forward_fn or (lambda inp: forward(sd, inp, encoder))
     depth_list, prev = [], None
     for slots in plan:
-        cur = [prev[k] if kind == "prev" else torch.from_numpy(normalize_frame(frames[k])) for kind, k in slots]
+        cur = [prev[k] if kind == "prev" else torch.from_numpy(preprocess_frame(frames[k], Hn, Wn)) for kind, k in slots]
         inp = torch.stack(cur, 0).unsqueeze(0)
         d = fwd(inp).float()
         d = F.interpolate(d.flatten(0, 1).unsqueeze(1), size=(H, W), mode="bilinear", align_corners=True)

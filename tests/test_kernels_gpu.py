@@ -310,6 +310,19 @@ def test_temporal_attention(B, T, hw, heads, hd, dt):
     close(out, want, OUT_TOL[dt], "temporal attention")
 
 
+@pytest.mark.parametrize("h0,w0,H,W", [(48, 86, 70, 126), (120, 200, 56, 98), (37, 53, 42, 56), (28, 42, 28, 42)])
+def test_preprocess_u8_against_cubic_restatement(h0, w0, H, W):
+    """uint8 frames -> /255 -> bicubic resize (OpenCV INTER_CUBIC arithmetic) -> normalisation, against the oracle's numpy
+    restatement of the same published arithmetic (parity with OpenCV itself is unpinned: cv2 is not available)."""
+    import vda_oracle as O
+    frames = np.random.RandomState(h0 + W).randint(0, 256, (3, h0, w0, 3), dtype=np.uint8)
+    out = torch.full((3, 3, H, W), float("nan"), dtype=torch.float32, device=DEV)
+    hip.preprocess_u8(torch.from_numpy(frames).to(DEV), out, 3, h0, w0, H, W)
+    want = np.stack([O.preprocess_frame(f, H, W) for f in frames])
+    err = np.abs(out.cpu().numpy() - want).max()
+    assert err <= 2e-5, f"max abs err {err:.3e}"          # values are O(1); both sides are fp32 sums of 16 taps
+
+
 def test_stitch_kernels():
     n = 300 * 200 * 2
     p = rnd((n,), 1, 1.0, torch.float32).abs() * 3 + 1

@@ -83,6 +83,19 @@ def test_forward_fp32_mode_matches_reference_goldens(golden_dir, vits, name, sha
     assert mr <= FP32_MODE_MAX_REL and ar <= FP32_MODE_MAX_REL
 
 
+@pytest.mark.parametrize("h0,w0,input_size,n", [(40, 72, 56, 34), (90, 60, 42, 5)])
+def test_whole_video_with_frame_resize_against_oracle(vits, h0, w0, input_size, n):
+    """Frames that are not at network size: aspect-ratio rule, bicubic resize on the device, depth resampled back to the
+    frame size; against the CPU oracle (whose resize restates OpenCV's arithmetic: that step's parity is unpinned)."""
+    model, sd = vits
+    frames = synth_frames(n, h0, w0, 900 + n)
+    got, _ = model.infer_video_depth(frames, 30, input_size=input_size, device="cuda", batch_size=32)
+    want = O.infer_video_depth(sd, list(frames), "vits", batch_size=32, input_size=input_size)
+    assert got.shape == want.shape == (n, h0, w0)
+    mr, ar = report(f"video with resize {h0}x{w0}->{O.network_size(h0, w0, input_size)}", got, want)
+    assert mr <= MAX_REL and ar <= ABS_REL
+
+
 def test_forward_mid_size_against_oracle(vits):
     """A larger, non-square input (resampled positional table, 10 x 14 patches) against the oracle run on the CPU."""
     model, sd = vits

@@ -116,3 +116,18 @@ def test_vitl_width_blocks(golden_dir):
     a = torch.from_numpy(rs.standard_normal((1, 256, 6, 5)).astype(np.float32))
     b = torch.from_numpy(rs.standard_normal((1, 256, 6, 5)).astype(np.float32))
     assert rel(O.fusion_block(big, 2, a, b, size=(12, 10)).numpy(), g["fusion"]) < TOL
+
+
+def test_cubic_resize_restatement_properties():
+    """The OpenCV-style bicubic restatement has no fixture to be pinned by; check what the arithmetic guarantees: identity
+    at equal size, constants preserved (the four weights sum to one), and exact 2x decimation phase (taps at +-0.5)."""
+    rs = np.random.RandomState(3)
+    img = rs.rand(12, 17, 3).astype(np.float32)
+    assert np.array_equal(O.cv_resize_cubic(img, 12, 17), img)
+    const = np.full((9, 11, 3), 0.37, np.float32)
+    assert np.abs(O.cv_resize_cubic(const, 20, 7) - 0.37).max() < 1e-6
+    ramp = np.tile(np.arange(16, dtype=np.float32)[None, :, None], (4, 1, 1))
+    half = O.cv_resize_cubic(ramp, 4, 8)                  # linear ramps are reproduced exactly away from the border
+    assert np.abs(half[:, 1:-1, 0] - (np.arange(8)[1:-1] * 2 + 0.5)).max() < 1e-5
+    frame = rs.randint(0, 256, (10, 14, 3), dtype=np.uint8)
+    assert np.array_equal(O.preprocess_frame(frame, 10, 14), O.normalize_frame(frame))
