@@ -96,6 +96,46 @@ def test_whole_video_with_frame_resize_against_oracle(vits, h0, w0, input_size, 
     assert mr <= MAX_REL and ar <= ABS_REL
 
 
+RANK_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {pkg!r})
+from video_depth_anything import spec
+from video_depth_anything.video_depth import VideoDepthAnything
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+torch.cuda.set_device(0)
+sd = {{k: torch.from_numpy(v) for k, v in spec.synth_state_dict(**spec.MODEL_CONFIGS["vits"], seed=1).items()}}
+m = VideoDepthAnything(**spec.MODEL_CONFIGS["vits"]); m.load_state_dict(sd, strict=True); m = m.to("cuda").eval()
+frames = np.load({frames!r})
+out, _ = m.infer_video_depth(frames, 30, input_size=28, device="cuda", batch_size=32)
+np.save(os.path.join({out!r}, "rank%d.npy" % dist.get_rank()), out)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world,n", [(2, 77), (3, 50)])
+def test_window_sharded_video_on_device_matches_single_process(vits, tmp_path, world, n):
+    """The multi-rank path of infer_video_depth with the real kernels: `world` processes share this one GPU (gloo carries
+    the all-gathers; on a node each rank has its own GPU and RCCL), every rank must return the single-process result."""
+    import socket, subprocess, sys
+    model, _ = vits
+    frames = synth_frames(n, 28, 42, 321 + n)
+    want, _ = model.infer_video_depth(frames, 30, input_size=28, device="cuda", batch_size=32)
+    np.save(tmp_path / "frames.npy", frames)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = RANK_WORKER.format(pkg=os.path.join(root, "monocular-depth-estimation_amd"), frames=str(tmp_path / "frames.npy"), out=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world),
+                                                                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npy")
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), (world, n, r)
+
+
 def test_forward_mid_size_against_oracle(vits):
     """A larger, non-square input (resampled positional table, 10 x 14 patches) against the oracle run on the CPU."""
     model, sd = vits
