@@ -168,12 +168,15 @@ int vda_temporal_attention(const void* qkv, void* out, int batch, int T, int hw,
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Window stitching (video_depth.py:166-205, utils/util.py:40-74).
- * vda_scale_shift_sums: sums[0..4] += {sum p*p, sum p, count, sum p*t, sum t} over n fp32 values (sums is 5 doubles,
- *   zeroed by the caller before the first call of a fit).
+ * vda_scale_shift_sums: sums[0..4] += {sum p*p, sum p, count, sum p*t, sum t} over n fp32 values.  `sums` holds
+ *   VDA_LSQ_SUMS_DOUBLES doubles: the five totals (zeroed by the caller before the first call of a fit) followed by
+ *   scratch for per-workgroup partial sums, which are added in a fixed order (no atomics: bit-identical results).
  * vda_affine_blend: out = w_pre * pre + w_post * max(scale * x + shift, 0)   over n fp32 values; scale/shift are read
  *   from device memory (ss[0], ss[1]) so no host round trip is needed; pre may be NULL when w_pre == 0.
  * vda_solve_scale_shift: one-thread 2x2 solve in fp32 from the five sums: ss = {scale, shift} ({1,0} if det == 0).
  * ------------------------------------------------------------------------------------------------------------- */
+#define VDA_LSQ_BLOCKS 256
+#define VDA_LSQ_SUMS_DOUBLES (5 + 4 * VDA_LSQ_BLOCKS)
 int vda_scale_shift_sums(const float* pred, const float* target, double* sums, long n, void* stream);
 int vda_solve_scale_shift(const double* sums, float* ss, void* stream);
 int vda_affine_blend(const float* x, const float* pre, float* out, const float* ss, float w_pre, float w_post, long n, void* stream);

@@ -3,8 +3,12 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void lsq_sums_kernel(const float* __restrict__ p, const float* __restrict__ t,
-                                                       double* __restrict__ sums, long n) {
+constexpr int LSQ_BLOCKS = VDA_LSQ_BLOCKS;
+
+// Pass 1: a fixed grid of LSQ_BLOCKS workgroups, each writes its four partial sums (double) to its own slot; pass 2 adds the
+// slots in order.  No atomics: the sums, and with them scale and shift, are bit-identical from run to run.
+__global__ __launch_bounds__(256) void lsq_partial_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                          double* __restrict__ part, long n) {
     __shared__ double red[4][4];
     double a00 = 0, a01 = 0, b0 = 0, b1 = 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -26,12 +30,20 @@ __global__ __launch_bounds__(256) void lsq_sums_kernel(const float* __restrict__
     __syncthreads();
     if (threadIdx.x < 4) {
         const int k = threadIdx.x;
-        const double tot = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        part[blockIdx.x * 4 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    }
+}
+
+__global__ void lsq_reduce_kernel(double* __restrict__ sums, const double* __restrict__ part, long n) {
+    const int k = threadIdx.x;                       // 0..3: sum p*p, sum p, sum p*t, sum t
+    if (k < 4) {
+        double tot = 0;
+        for (int b = 0; b < LSQ_BLOCKS; ++b) tot += part[b * 4 + k];
         // sums layout: {sum p*p, sum p, count, sum p*t, sum t}
         const int slot = k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 3 : 4;
-        atomicAdd(&sums[slot], tot);
+        sums[slot] += tot;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 4) atomicAdd(&sums[2], (double)n);
+    if (k == 4) sums[2] += (double)n;
 }
 
 // The solve repeats the reference's float32 arithmetic on float32-rounded sums (utils/util.py:46-60).
@@ -71,8 +83,10 @@ inline int grid_for(long n) {
 
 extern "C" int vda_scale_shift_sums(const float* pred, const float* target, double* sums, long n, void* stream) {
     if (!pred || !target || !sums || n <= 0) return VDA_EINVAL;
-    hipLaunchKernelGGL(lsq_sums_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pred, target,
-                       sums, n);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    double* part = sums + 5;                         // LSQ_BLOCKS x 4 partial sums behind the five totals
+    hipLaunchKernelGGL(lsq_partial_kernel, dim3(LSQ_BLOCKS), dim3(256), 0, s, pred, target, part, n);
+    hipLaunchKernelGGL(lsq_reduce_kernel, dim3(1), dim3(64), 0, s, sums, part, n);
     return hip_rc(hipGetLastError());
 }
 

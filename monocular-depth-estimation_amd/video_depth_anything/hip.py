@@ -17,6 +17,7 @@ ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 T_NONE, T_F32, T_BF16, T_F16 = 0, 1, 2, 3
 EPI_PLAIN, EPI_GEGLU, EPI_CONVT, EPI_DOT = 0, 1, 2, 3
 GROUPNORM_MAX_SPLITS = 64        # VDA_GROUPNORM_MAX_SPLITS: sizes the scratch of groupnorm()
+LSQ_SUMS_DOUBLES = 5 + 4 * 256   # VDA_LSQ_SUMS_DOUBLES: five totals + per-workgroup partials of scale_shift_sums()
 
 EXPORTS = [
     "vda_version", "vda_gemm", "vda_attention", "vda_layernorm", "vda_groupnorm", "vda_bilinear_nhwc", "vda_bilinear_f32",

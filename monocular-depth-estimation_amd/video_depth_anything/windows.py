@@ -94,7 +94,7 @@ class Stitcher:
         self.tail = None          # last 8 aligned maps (still open for blending)
         self.ref0 = None
         self.ref1 = None
-        self.sums = torch.zeros(5, dtype=torch.float64, device=device)
+        self.sums = torch.zeros(hip.LSQ_SUMS_DOUBLES, dtype=torch.float64, device=device)   # 5 totals + partial-sum scratch
         self.ss = torch.zeros(2, dtype=torch.float32, device=device)
         self.started = False
 

@@ -103,10 +103,10 @@ def _standins(monkeypatch):
 
     def scale_shift_sums(p, t, sums, n):
         p, t = p.double().reshape(-1), t.double().reshape(-1)
-        sums += torch.stack([(p * p).sum(), p.sum(), torch.tensor(float(n), dtype=torch.float64), (p * t).sum(), t.sum()])
+        sums[:5] += torch.stack([(p * p).sum(), p.sum(), torch.tensor(float(n), dtype=torch.float64), (p * t).sum(), t.sum()])
 
     def solve_scale_shift(sums, ss):
-        a00, a01, a11, b0, b1 = [np.float32(v) for v in sums.tolist()]
+        a00, a01, a11, b0, b1 = [np.float32(v) for v in sums[:5].tolist()]
         det = a00 * a11 - a01 * a01
         ss[0], ss[1] = (1.0, 0.0) if det == 0 else (float((a11 * b0 - a01 * b1) / det), float((-a01 * b0 + a00 * b1) / det))
 

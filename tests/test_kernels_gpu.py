@@ -327,8 +327,12 @@ def test_stitch_kernels():
     n = 300 * 200 * 2
     p = rnd((n,), 1, 1.0, torch.float32).abs() * 3 + 1
     t = 1.7 * p + 0.3 + rnd((n,), 2, 0.01, torch.float32)
-    sums = torch.zeros(5, dtype=torch.float64, device=DEV)
-    hip.scale_shift_sums(p, t, sums, n)
+    sums_all = torch.zeros(hip.LSQ_SUMS_DOUBLES, dtype=torch.float64, device=DEV)
+    hip.scale_shift_sums(p, t, sums_all, n)
+    again = torch.zeros_like(sums_all)
+    hip.scale_shift_sums(p, t, again, n)
+    assert torch.equal(sums_all[:5], again[:5])             # fixed summation order: bit-identical
+    sums = sums_all[:5]
     pd, td = p.double(), t.double()
     want = torch.stack([(pd * pd).sum(), pd.sum(), torch.tensor(float(n), device=DEV, dtype=torch.float64), (pd * td).sum(), td.sum()])
     assert torch.allclose(sums, want, rtol=1e-12)
