@@ -89,11 +89,21 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
     const int wave_n0 = ncol0 - fq * 4;
     const int out_n0 = geglu ? wave_n0 / 2 : wave_n0;        // first output column of the block
     const int n_out = geglu ? p.N / 2 : p.N;
+    // transposed convolution: the block's columns are channels co0.. of one kernel tap (ky, kx), because ct_c is a
+    // multiple of the block width; row m = (iy, x) goes to output pixel (iy ct_k + ky, x ct_k + kx)
+    const bool convt = p.epi == VDA_EPI_CONVT;
+    int tap_n0 = 0, ct_ky = 0, ct_kx = 0;
+    if (convt) {
+        const int tap = wave_n0 / p.ct_c;
+        tap_n0 = tap * p.ct_c;
+        ct_ky = tap / p.ct_k;
+        ct_kx = tap - ct_ky * p.ct_k;
+    }
     f32x4 bias[TN], gam[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = ncol0 + j * 16;
-        bias[j] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bias[j] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n - tap_n0) : f32x4{0.f, 0.f, 0.f, 0.f};
         gam[j] = (p.gamma && n < p.N) ? *reinterpret_cast<const f32x4*>(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
     }
     const int c_row = lane / cpr, c_chunk = lane - c_row * cpr;
@@ -137,8 +147,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
                 const int mm = mbase + row;
                 const int col = (c_chunk << 4) / esz;          // first output column of this lane's chunk
                 const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * rs + (c_chunk << 4));
-                if (mm < p.M && out_n0 + col < n_out)
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.out) + ((size_t)mm * p.ldc + out_n0 + col) * esz) = v;
+                if (mm < p.M && out_n0 + col < n_out) {
+                    size_t pix = mm;
+                    if (convt) {
+                        const int iy = mm / p.ct_w, x = mm - iy * p.ct_w;     // iy = img * ct_h + y
+                        pix = ((size_t)iy * p.ct_k + ct_ky) * (p.ct_w * p.ct_k) + (size_t)x * p.ct_k + ct_kx;
+                    }
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.out) + (pix * p.ldc + out_n0 - tap_n0 + col) * esz) = v;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads returned before the next m-tile overwrites the area
@@ -148,13 +164,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq,
                                               char* stage = nullptr) {
-    if (stage && (p.epi == VDA_EPI_PLAIN || p.epi == VDA_EPI_GEGLU)) {
+    if (stage && (p.epi == VDA_EPI_PLAIN || p.epi == VDA_EPI_GEGLU || p.epi == VDA_EPI_CONVT)) {
         const int esz = p.out_type == VDA_T_F32 ? 4 : 2;
         const int n_out = p.epi == VDA_EPI_GEGLU ? p.N / 2 : p.N;
         const int cols = p.epi == VDA_EPI_GEGLU ? TN * 8 : TN * 16;
-        // 16-byte row alignment of the output, whole chunks inside N, and at most 64 chunks per 16-row block row set
+        // 16-byte row alignment of the output, whole chunks inside N, and at most 64 chunks per 16-row block row set;
+        // for the transposed convolution a block must not straddle two kernel taps
         if ((p.ldc * esz) % 16 == 0 && (n_out * esz) % 16 == 0 && (cols * esz) % 16 == 0 && (cols * esz) <= 256 &&
-            ((uintptr_t)p.out & 15) == 0) {
+            ((uintptr_t)p.out & 15) == 0 && (p.epi != VDA_EPI_CONVT || p.ct_c % cols == 0)) {
             gemm_epilogue_staged<TM, TN>(p, acc, mrow0, ncol0, fq, stage);
             return;
         }

@@ -97,7 +97,7 @@ def test_gemm_geglu(dt, cfg):
 
 
 @pytest.mark.parametrize("cfg", TILE_CFGS)
-@pytest.mark.parametrize("k,C", [(4, 64), (2, 128)])
+@pytest.mark.parametrize("k,C", [(4, 64), (2, 128), (2, 96)])   # 96: a 64-column block straddles two taps (unstaged stores)
 def test_gemm_conv_transpose(k, C, cfg):
     B, h, w_ = 3, 5, 7
     x = rnd((B, C, h, w_), 1)
