@@ -84,6 +84,11 @@ typedef struct VdaGemmArgs {
     int tile_cfg;         /* 0 = the library picks the kernel; 1..3 force one where the call allows it (tuning and tests):
                              1 = 128x128 tile / 4 waves, 2 = 256x256 tile / 8 waves, 4-phase pipelined, 3 = direct 3x3
                              convolution (stride 1, N = 32, 64 or a multiple of 128, no gamma); other values are VDA_EINVAL */
+    int up_h, up_w;       /* CONV3 only; 0 = off.  Otherwise `a` is the NHWC map [img][up_h][up_w][cin] and the convolution
+                             input is its bilinear resampling (align_corners=True, arithmetic of vda_bilinear_nhwc) to
+                             in_h x in_w, computed while the input patches are loaded: the resampled map never exists in
+                             memory (util/blocks.py:154-158 -> :160 and dpt_temporal.py:88,97-100 -> dpt.py:118-119).
+                             Only where the direct 3x3 kernel applies (see tile_cfg 3), else VDA_ESHAPE              */
 } VdaGemmArgs;
 
 int vda_gemm(const VdaGemmArgs* args, void* stream);

@@ -15,6 +15,10 @@
 // copies of the next step; wait until everything but those has landed (counted vmcnt; copies retire in issue order);
 // barrier; MFMAs; barrier (the buffers may be refilled).
 //
+// Fused upsampling (UP): the convolution input is the bilinear (align_corners) resampling of a smaller map.  The halo is
+// then not copied but computed: each lane loads the four source pixels of its 16-byte piece, blends them in fp32 and
+// writes the piece to the same LDS slot, so the resampled map (4 - 12 x the source) is never written to or read from HBM.
+//
 // LDS images are lane-linear (global_load_lds); halo pixel hp keeps its 16-byte channel chunk c at slot c ^ (hp & 7),
 // which is conflict-free for the ds_read_b128 lane groups at any starting pixel of a 16-pixel run; weight rows use the
 // common tile_off() swizzle.
@@ -29,7 +33,55 @@ constexpr int HALO_W = PT_W + 2, HALO_H = PT_H + 2, HALO_PX = HALO_W * HALO_H;
 constexpr int HALO_ITERS = (HALO_PX * 8 + 255) / 256;      // 16-byte pieces per thread and slice
 constexpr int HALO_BYTES = HALO_ITERS * 256 * 16;          // whole iterations: lanes past the last pixel copy zeros into the pad
 
-template <int TN, int TPS, bool RELU_IN, typename T>
+// Mixed-precision FMA: one fp16 half of a packed register times an fp32 weight plus an fp32 addend, with no separate
+// conversion instruction; the last step of a chain rounds to fp16 (nearest even) into one half of the destination.
+template <int HI>
+__device__ __forceinline__ float mix_fma(unsigned h2, float w, float c) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(w), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(w), "v"(c));
+    return r;
+}
+// low half first: it defines the register (the other half is then still unspecified), the high half completes it
+__device__ __forceinline__ unsigned mix_fma_to_lo(unsigned h2, float w, float c) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(w), "v"(c));
+    return d;
+}
+__device__ __forceinline__ void mix_fma_to_hi(unsigned& d, unsigned h2, float w, float c) {
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(h2), "v"(w), "v"(c));
+}
+
+// sum_j w[j] * q[j] over four 16-byte pieces of 8 values of type T, accumulated in fp32 and rounded once
+template <typename T>
+__device__ __forceinline__ u32x4 blend4(const u32x4 (&q)[4], float w0, float w1, float w2, float w3);
+template <>
+__device__ __forceinline__ u32x4 blend4<f16>(const u32x4 (&q)[4], float w0, float w1, float w2, float w3) {
+    u32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float lo = mix_fma<0>(q[0][r], w0, 0.f), hi = mix_fma<1>(q[0][r], w0, 0.f);
+        lo = mix_fma<0>(q[1][r], w1, lo);
+        hi = mix_fma<1>(q[1][r], w1, hi);
+        lo = mix_fma<0>(q[2][r], w2, lo);
+        hi = mix_fma<1>(q[2][r], w2, hi);
+        unsigned d = mix_fma_to_lo(q[3][r], w3, lo);
+        mix_fma_to_hi(d, q[3][r], w3, hi);
+        o[r] = d;
+    }
+    return o;
+}
+template <>
+__device__ __forceinline__ u32x4 blend4<bf16>(const u32x4 (&q)[4], float w0, float w1, float w2, float w3) {
+    bf16x8 v[4], o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(bf16x8, q[j]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (bf16)(w0 * (float)v[0][k] + w1 * (float)v[1][k] + w2 * (float)v[2][k] + w3 * (float)v[3][k]);
+    return __builtin_bit_cast(u32x4, o);
+}
+
+template <int TN, int TPS, bool RELU_IN, bool UP, typename T>
 __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs p, const int tiles_x, const int tiles_y) {
     typedef typename Vec<T>::v8 frag_t;
     constexpr int N = TN * 16;
@@ -46,20 +98,23 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     const int ty = (blockIdx.x / tiles_x) % tiles_y;
     const int img = blockIdx.x / (tiles_x * tiles_y);
     const int oy0 = ty * PT_H, ox0 = tx * PT_W;
-    const bf16* a_img = reinterpret_cast<const bf16*>(p.a) + (size_t)img * p.in_h * p.in_w * p.cin;
+    const int src_h = UP ? p.up_h : p.in_h, src_w = UP ? p.up_w : p.in_w;     // size of the map in memory
+    const bf16* a_img = reinterpret_cast<const bf16*>(p.a) + (size_t)img * src_h * src_w * p.cin;
     const bf16* zsrc = reinterpret_cast<const bf16*>(p.zeros);
     const int n0 = blockIdx.y * N;                           // first output channel of this workgroup
 
     // ---- copy sources (element offsets inside the image; -1 = padding or pad lanes: copy zeros) ------------------------------
-    int hoff[HALO_ITERS];
+    int hoff[UP ? 1 : HALO_ITERS];
+    if (!UP) {
 #pragma unroll
-    for (int it = 0; it < HALO_ITERS; ++it) {
-        const int piece = it * 256 + tid;
-        const int hp = piece >> 3, slot = piece & 7;
-        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-        const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-        const bool ok = hp < HALO_PX && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
-        hoff[it] = ok ? (iy * p.in_w + ix) * p.cin + ((slot ^ (hp & 7)) << 3) : -1;
+        for (int it = 0; it < HALO_ITERS; ++it) {
+            const int piece = it * 256 + tid;
+            const int hp = piece >> 3, slot = piece & 7;
+            const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+            const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+            const bool ok = hp < HALO_PX && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
+            hoff[UP ? 0 : it] = ok ? (iy * p.in_w + ix) * p.cin + ((slot ^ (hp & 7)) << 3) : -1;
+        }
     }
     int woff[W_ITERS];
 #pragma unroll
@@ -72,9 +127,53 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     auto issue_halo = [&](int cc) {
 #pragma unroll
         for (int it = 0; it < HALO_ITERS; ++it) {
-            const bf16* s = hoff[it] >= 0 ? a_img + hoff[it] + cc * 64 : zsrc;
+            const bf16* s = hoff[UP ? 0 : it] >= 0 ? a_img + hoff[UP ? 0 : it] + cc * 64 : zsrc;
             glds16(s, halo + (it * 256 + wave * 64) * 16);
         }
+    };
+    // UP: blend the four source pixels of every piece and write it where the copy would have put it.  The source
+    // positions are recomputed per piece (a few instructions against four loads) rather than kept in registers.
+    const float up_sy = UP && p.in_h > 1 ? (float)(src_h - 1) / (float)(p.in_h - 1) : 0.f;
+    const float up_sx = UP && p.in_w > 1 ? (float)(src_w - 1) / (float)(p.in_w - 1) : 0.f;
+    auto blend_halo = [&](int cc) {
+        constexpr int G = TN >= 8 ? 2 : 4;                   // pieces whose 4 loads each are in flight together (registers)
+        const unsigned px_step = p.cin * sizeof(T), row_step = src_w * px_step;
+        const char* a_cc = reinterpret_cast<const char*>(a_img) + cc * 128;       // wave-uniform base, 32-bit byte offsets
+#pragma unroll 1
+        for (int g0 = 0; g0 < HALO_ITERS; g0 += G) {
+            u32x4 q[G][4];
+            float wx1[G], wy1[G];
+            bool okg[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int piece = (g0 + g) * 256 + tid;
+                const int hp = piece >> 3, slot = piece & 7;
+                const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+                const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+                const bool ok = hp < HALO_PX && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
+                const float fy = up_sy * (float)iy, fx = up_sx * (float)ix;      // ATen: src = scale * dst, i0 = (int)src
+                const int y0 = (int)fy, x0 = (int)fx;
+                wy1[g] = fy - (float)y0;
+                wx1[g] = fx - (float)x0;
+                okg[g] = ok;
+                // pieces outside the image read the first pixel (in bounds) and are written as zeros
+                const unsigned dx = ok && x0 < src_w - 1 ? px_step : 0, dy = ok && y0 < src_h - 1 ? row_step : 0;
+                const unsigned o00 = ok ? (unsigned)(y0 * src_w + x0) * px_step + ((slot ^ (hp & 7)) << 4) : 0;
+                q[g][0] = *reinterpret_cast<const u32x4*>(a_cc + o00);
+                q[g][1] = *reinterpret_cast<const u32x4*>(a_cc + (o00 + dx));
+                q[g][2] = *reinterpret_cast<const u32x4*>(a_cc + (o00 + dy));
+                q[g][3] = *reinterpret_cast<const u32x4*>(a_cc + (o00 + dy + dx));
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float w00 = (1.f - wy1[g]) * (1.f - wx1[g]), w01 = (1.f - wy1[g]) * wx1[g];
+                const float w10 = wy1[g] * (1.f - wx1[g]), w11 = wy1[g] * wx1[g];
+                u32x4 o = blend4<T>(q[g], w00, w01, w10, w11);
+                if (!okg[g]) o = u32x4{0u, 0u, 0u, 0u};
+                if (g0 + g < HALO_ITERS) *reinterpret_cast<u32x4*>(halo + ((g0 + g) * 256 + tid) * 16) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the writes have landed before this wave reaches the barrier
     };
     auto issue_w = [&](int s, int buf) {
         const int cc = s / SPC, tap0 = (s - cc * SPC) * TPS;
@@ -103,7 +202,9 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     issue_w(0, 0);
     for (int s = 0; s < steps; ++s) {
         const int cc = s / SPC, tg = s - cc * SPC;
-        if (tg == 0) issue_halo(cc);                         // all reads of the previous slice ended at the last barrier
+        if (tg == 0) {                                       // all reads of the previous slice ended at the last barrier
+            if (UP) blend_halo(cc); else issue_halo(cc);
+        }
         if (s + 1 < steps) {
             issue_w(s + 1, (s + 1) & 1);
             if (W_ITERS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -206,27 +307,28 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     }
 }
 
-template <int TN, int TPS, bool RELU_IN, typename T>
+template <int TN, int TPS, bool RELU_IN, bool UP, typename T>
 int launch_cfg(const VdaGemmArgs& a, hipStream_t s) {
     const int tiles_x = (a.out_w + PT_W - 1) / PT_W, tiles_y = (a.out_h + PT_H - 1) / PT_H;
     const int imgs = a.M / (a.out_h * a.out_w);
     const int lds = HALO_BYTES + 2 * TPS * TN * 16 * 128;
-    auto k = conv3_direct_kernel<TN, TPS, RELU_IN, T>;
+    auto k = conv3_direct_kernel<TN, TPS, RELU_IN, UP, T>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(imgs * tiles_x * tiles_y), a.N / (TN * 16)), dim3(256), lds, s, a, tiles_x, tiles_y);
     return hip_rc(hipGetLastError());
 }
 
-template <bool RELU_IN, typename T>
+template <bool RELU_IN, bool UP, typename T>
 int launch_r(const VdaGemmArgs& a, hipStream_t s) {
-    if (a.N % 128 == 0) return launch_cfg<8, 1, RELU_IN, T>(a, s);
-    if (a.N == 64) return launch_cfg<4, 3, RELU_IN, T>(a, s);
-    return launch_cfg<2, 3, RELU_IN, T>(a, s);
+    if (a.N % 128 == 0) return launch_cfg<8, 1, RELU_IN, UP, T>(a, s);
+    if (a.N == 64) return launch_cfg<4, 3, RELU_IN, UP, T>(a, s);
+    return launch_cfg<2, 3, RELU_IN, UP, T>(a, s);
 }
 
 template <typename T>
 int launch_t(const VdaGemmArgs& a, hipStream_t s) {
-    return a.relu_in ? launch_r<true, T>(a, s) : launch_r<false, T>(a, s);
+    if (a.up_h > 0) return a.relu_in ? launch_r<true, true, T>(a, s) : launch_r<false, true, T>(a, s);
+    return a.relu_in ? launch_r<true, false, T>(a, s) : launch_r<false, false, T>(a, s);
 }
 
 }  // namespace
@@ -241,6 +343,7 @@ bool conv_direct_supports(const VdaGemmArgs& a) {
     const int esz = a.out_type == VDA_T_F32 ? 4 : 2;
     if ((a.ldc * esz) % 16 != 0 || ((uintptr_t)a.out & 15) != 0 || a.ldc < a.N) return false;
     if ((long)a.in_h * a.in_w * a.cin > 0x7fffffffL) return false;       // 32-bit element offsets inside one image
+    if (a.up_h > 0 && (long)a.up_h * a.up_w * a.cin > 0x7fffffffL) return false;
     return a.M % (a.out_h * a.out_w) == 0;
 }
 

@@ -48,8 +48,22 @@ class Engine:
         hip.gemm(a, w, out, M=M, N=N, K=K, lda=a.stride(0), ldc=kw.pop("ldc", out.stride(0)), bias=bias, **kw)
         return out
 
-    def conv3(self, x, w, bias, cout, stride=1, relu_in=False, out=None, ldc=None, **kw):
-        """x: [frames, h, w, cin] -> [frames, oh, ow, cout] (3x3, padding 1), both of the head's storage type."""
+    def conv3(self, x, w, bias, cout, stride=1, relu_in=False, out=None, ldc=None, resized=None, **kw):
+        """x: [frames, h, w, cin] -> [frames, oh, ow, cout] (3x3, padding 1), both of the head's storage type.
+        ``resized=(h', w')``: the convolution runs on the bilinear resampling of x to h' x w'; with 16-bit storage the
+        kernel resamples while it loads its input patches and the resized map is never materialised."""
+        if resized is not None and tuple(resized) != tuple(x.shape[1:3]):
+            if self.split or stride != 1:
+                x = self.resize(x, *resized)
+            else:
+                f, sh, sw, cin = x.shape
+                h, wd = resized
+                if out is None:
+                    out = _empty((f, h, wd, cout), self.hdt, self.dev)
+                hip.gemm(x.reshape(f * sh * sw, cin), w, out, M=f * h * wd, N=cout, K=9 * cin, lda=0,
+                         ldc=cout if ldc is None else ldc, bias=bias, relu_in=relu_in, conv=(h, wd, cin, h, wd, 1),
+                         upsample_from=(sh, sw), **kw)
+                return out
         f, h, wd, cin = x.shape
         oh, ow = (h - 1) // stride + 1, (wd - 1) // stride + 1
         if out is None:
@@ -131,7 +145,7 @@ class Engine:
         return out
 
     # ---- RefineNet fusion (reference: util/blocks.py:68-91, 135-162) -----------------------------------------------------
-    def fusion(self, idx, x0, x1, oh, ow):
+    def fusion(self, idx, x0, x1, oh, ow, resize=True):
         r, Fp = self.w.refine[idx], self.w.Fp
         y = x0
         if x1 is not None:
@@ -144,7 +158,7 @@ class Engine:
         f, h, wd, _ = z.shape
         zc = _empty((f, h, wd, Fp), self.hdt, self.dev)
         self.linear(z.reshape(-1, Fp), r["out_w"], zc.reshape(-1, Fp), r["out_b"])
-        return self.resize(zc, oh, ow)
+        return self.resize(zc, oh, ow) if resize else zc
 
     # ---- DPT head (reference: dpt_temporal.py:53-114, dpt.py:60-124) ---------------------------------------------------
     def head(self, taps, B, T, hp, wp):
@@ -173,11 +187,12 @@ class Engine:
         p3 = self.fusion(3, p4, r3, 2 * hp, 2 * wp)
         p3 = self.motion(3, p3, B, T)
         p2 = self.fusion(2, p3, r2, 4 * hp, 4 * wp)
-        p1 = self.fusion(1, p2, r1, 8 * hp, 8 * wp)
-        o1 = self.conv3(p1, w.oc1_w, w.oc1_b, w.F2p)
-        o1 = self.resize(o1, 14 * hp, 14 * wp)
+        # the two largest resamplings (to 8x and 14x the patch grid) are folded into the convolutions that read them
+        p1 = self.fusion(1, p2, r1, 8 * hp, 8 * wp, resize=False)
+        o1 = self.conv3(p1, w.oc1_w, w.oc1_b, w.F2p, resized=(8 * hp, 8 * wp))
         depth = _empty((frames, 14 * hp, 14 * wp), torch.float32, dev)
-        self.conv3(o1, w.oc2_w, w.oc2_b, 32, out=depth, ldc=4, epi=hip.EPI_DOT, dot_w=w.dot_w, dot_b=w.dot_b)
+        self.conv3(o1, w.oc2_w, w.oc2_b, 32, out=depth, ldc=4, epi=hip.EPI_DOT, dot_w=w.dot_w, dot_b=w.dot_b,
+                   resized=(14 * hp, 14 * wp))
         return depth
 
     def forward(self, x):

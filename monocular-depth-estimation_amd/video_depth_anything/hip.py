@@ -36,6 +36,7 @@ class GemmArgs(C.Structure):
         ("ab_type", C.c_int), ("relu_in", C.c_int),
         ("in_h", C.c_int), ("in_w", C.c_int), ("cin", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int), ("stride", C.c_int),
         ("ct_h", C.c_int), ("ct_w", C.c_int), ("ct_k", C.c_int), ("ct_c", C.c_int), ("tile_cfg", C.c_int),
+        ("up_h", C.c_int), ("up_w", C.c_int),
     ]
 
 
@@ -113,8 +114,9 @@ def zero_page(device):
 
 
 def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr=0, resid2=None, ldr2=0, act=ACT_NONE,
-         epi=EPI_PLAIN, relu_in=False, conv=None, convt=None, dot_w=None, dot_b=0.0, tile_cfg=None):
-    """Enqueue one vda_gemm.  ``conv`` = (in_h, in_w, cin, out_h, out_w, stride); ``convt`` = (h, w, k, c)."""
+         epi=EPI_PLAIN, relu_in=False, conv=None, convt=None, dot_w=None, dot_b=0.0, tile_cfg=None, upsample_from=None):
+    """Enqueue one vda_gemm.  ``conv`` = (in_h, in_w, cin, out_h, out_w, stride); ``convt`` = (h, w, k, c);
+    ``upsample_from`` = (h, w) of the map ``a`` that is bilinearly resampled to in_h x in_w on the fly."""
     _dev(a, w, out, bias, gamma, resid, resid2, dot_w)
     g = GemmArgs()
     g.a, g.w, g.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -138,6 +140,8 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
         g.a_mode = A_CONV3
         g.in_h, g.in_w, g.cin, g.out_h, g.out_w, g.stride = conv
         g.zeros = zero_page(a.device).data_ptr()
+        if upsample_from is not None:
+            g.up_h, g.up_w = upsample_from
     else:
         g.a_mode = A_LINEAR
     if convt is not None:

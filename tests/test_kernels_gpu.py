@@ -97,17 +97,17 @@ def test_gemm_geglu(dt, cfg):
 
 
 @pytest.mark.parametrize("cfg", TILE_CFGS)
-@pytest.mark.parametrize("k,C", [(4, 64), (2, 128), (2, 96)])   # 96: a 64-column block straddles two taps (unstaged stores)
-def test_gemm_conv_transpose(k, C, cfg):
+@pytest.mark.parametrize("k,C,Co", [(4, 64, 64), (2, 128, 128), (2, 64, 96)])   # 96: a 64-column block straddles two taps (unstaged stores)
+def test_gemm_conv_transpose(k, C, Co, cfg):
     B, h, w_ = 3, 5, 7
     x = rnd((B, C, h, w_), 1)
-    wt = rnd((C, C, k, k), 2, 1 / math.sqrt(C))          # [Cin, Cout, k, k]
-    bias = rnd((C,), 3, 0.1, torch.float32)
+    wt = rnd((C, Co, k, k), 2, 1 / math.sqrt(C))          # [Cin, Cout, k, k]
+    bias = rnd((Co,), 3, 0.1, torch.float32)
     want = F.conv_transpose2d(x.float(), wt.float(), bias, stride=k).permute(0, 2, 3, 1)
     a = x.permute(0, 2, 3, 1).reshape(B * h * w_, C).contiguous()
-    wg = wt.permute(2, 3, 1, 0).reshape(k * k * C, C).contiguous()       # n = (ky*k+kx)*C + co, k-dim = ci
-    out = torch.full((B, h * k, w_ * k, C), float("nan"), dtype=BF, device=DEV)
-    hip.gemm(a, wg, out, M=B * h * w_, N=k * k * C, K=C, lda=C, ldc=C, bias=bias, epi=hip.EPI_CONVT, convt=(h, w_, k, C), tile_cfg=cfg)
+    wg = wt.permute(2, 3, 1, 0).reshape(k * k * Co, C).contiguous()       # n = (ky*k+kx)*Co + co, k-dim = ci
+    out = torch.full((B, h * k, w_ * k, Co), float("nan"), dtype=BF, device=DEV)
+    hip.gemm(a, wg, out, M=B * h * w_, N=k * k * Co, K=C, lda=C, ldc=Co, bias=bias, epi=hip.EPI_CONVT, convt=(h, w_, k, Co), tile_cfg=cfg)
     close(out, want, BF_OUT, "convT")
 
 
@@ -186,6 +186,58 @@ def test_conv3x3_direct_kernel_residual_unit(B, h, w_, C):
         close(out, want, BF_OUT, f"residual unit conv cfg {cfg}")
         outs.append(out)
     close(outs[1], outs[0], 1e-3, "direct vs implicit GEMM")      # same products; the fp32 accumulation order differs
+
+
+@pytest.mark.parametrize("dt", HALVES)
+@pytest.mark.parametrize("B,sh,sw,h,w_,cin,cout,mode", [
+    (2, 10, 23, 20, 46, 128, 128, "relu"),        # x2 as in the last fusion block, patches cut by both borders
+    (1, 21, 17, 37, 30, 128, 32, "dot"),          # x1.75 as before the output tail, fused 1x1 tail
+    (2, 9, 9, 33, 65, 64, 64, "plain"),           # 64 output channels, one channel slice, large ratios
+    (1, 12, 40, 12, 80, 192, 256, "plain"),       # one axis unchanged; two 128-channel workgroup columns; three slices
+    (1, 1, 1, 5, 7, 64, 32, "relu_in"),           # single source pixel: every sample is that pixel
+])
+def test_conv3x3_direct_kernel_with_fused_bilinear_input(B, sh, sw, h, w_, cin, cout, mode, dt):
+    """conv3x3(bilinear(x, align_corners=True)) with the resampling done inside the convolution's patch loader
+    (util/blocks.py:154-160, dpt_temporal.py:88-100): against torch in fp32 on the same 16-bit inputs, and against this
+    library's own two-kernel sequence, whose intermediate map is rounded to 16 bits exactly like the fused patch."""
+    x = rnd((B, sh, sw, cin), 1, 1.0, dt)
+    wt = rnd((cout, cin, 3, 3), 2, 1 / math.sqrt(9 * cin), dt)
+    bias = rnd((cout,), 3, 0.1, torch.float32)
+    wg = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
+    up = F.interpolate(x.float().permute(0, 3, 1, 2), size=(h, w_), mode="bilinear", align_corners=True)
+    up16 = torch.empty((B, h, w_, cin), dtype=dt, device=DEV)
+    hip.bilinear_nhwc(x, up16, B, sh, sw, h, w_, cin)
+    close(up16, up.permute(0, 2, 3, 1), 5e-3, "bilinear")
+    kw = dict(M=B * h * w_, N=cout, K=9 * cin, lda=0, bias=bias)
+    if mode == "dot":
+        dw, db = rnd((32,), 4, 0.3, torch.float32), 0.05
+        want = F.relu((F.relu(F.conv2d(up16.float().permute(0, 3, 1, 2), wt.float(), bias, padding=1)) * dw.view(1, -1, 1, 1)).sum(1) + db)
+        fused = torch.full((B, h, w_), float("nan"), dtype=torch.float32, device=DEV)
+        two = torch.full_like(fused, float("nan"))
+        kw.update(ldc=4, epi=hip.EPI_DOT, dot_w=dw, dot_b=db)
+        tol = 2e-3
+    else:
+        xin = up16.float().permute(0, 3, 1, 2)
+        want = F.conv2d(F.relu(xin) if mode == "relu_in" else xin, wt.float(), bias, padding=1)
+        want = (F.relu(want) if mode == "relu" else want).permute(0, 2, 3, 1)
+        fused = torch.full((B, h, w_, cout), float("nan"), dtype=dt, device=DEV)
+        two = torch.full_like(fused, float("nan"))
+        kw.update(ldc=cout, act=hip.ACT_RELU if mode == "relu" else hip.ACT_NONE, relu_in=mode == "relu_in")
+        tol = BF_OUT
+    hip.gemm(x, wg, fused, conv=(h, w_, cin, h, w_, 1), upsample_from=(sh, sw), **kw)
+    hip.gemm(up16, wg, two, conv=(h, w_, cin, h, w_, 1), tile_cfg=3, **kw)
+    close(fused, want, tol, "fused vs torch")
+    # the two paths may round a resampled value to different neighbours (fp32 blend order), which can move an output
+    # by one unit of its 16-bit rounding, nothing more
+    close(fused, two, tol, "fused vs bilinear kernel + direct convolution")
+
+
+def test_fused_bilinear_input_is_refused_where_the_direct_kernel_does_not_apply():
+    x = rnd((1, 5, 5, 64), 1, 1.0, torch.float16)
+    wg = rnd((48, 9 * 64), 2, 0.1, torch.float16)
+    out = torch.empty((1, 10, 10, 48), dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError):                                   # 48 output channels: no direct kernel, no silent fallback
+        hip.gemm(x, wg, out, M=100, N=48, K=9 * 64, lda=0, ldc=48, conv=(10, 10, 64, 10, 10, 1), upsample_from=(5, 5))
 
 
 @pytest.mark.parametrize("frames,n_tok,heads", [(2, 1370, 6), (3, 64, 2), (1, 129, 16), (2, 36, 1), (1, 4100, 2), (1, 5477, 1)])
