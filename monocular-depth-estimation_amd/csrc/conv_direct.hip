@@ -81,8 +81,32 @@ __device__ __forceinline__ u32x4 blend4<bf16>(const u32x4 (&q)[4], float w0, flo
     return __builtin_bit_cast(u32x4, o);
 }
 
+// w0 * a + w1 * b over two 16-byte pieces, likewise
+template <typename T>
+__device__ __forceinline__ u32x4 blend2(const u32x4& a, const u32x4& b, float w0, float w1);
+template <>
+__device__ __forceinline__ u32x4 blend2<f16>(const u32x4& a, const u32x4& b, float w0, float w1) {
+    u32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float lo = mix_fma<0>(a[r], w0, 0.f), hi = mix_fma<1>(a[r], w0, 0.f);
+        unsigned d = mix_fma_to_lo(b[r], w1, lo);
+        mix_fma_to_hi(d, b[r], w1, hi);
+        o[r] = d;
+    }
+    return o;
+}
+template <>
+__device__ __forceinline__ u32x4 blend2<bf16>(const u32x4& a, const u32x4& b, float w0, float w1) {
+    const bf16x8 va = __builtin_bit_cast(bf16x8, a), vb = __builtin_bit_cast(bf16x8, b);
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (bf16)(w0 * (float)va[k] + w1 * (float)vb[k]);
+    return __builtin_bit_cast(u32x4, o);
+}
+
 template <int TN, int TPS, bool RELU_IN, bool UP, typename T>
-__global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs p, const int tiles_x, const int tiles_y) {
+__global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs p, const int tiles_x, const int tiles_y, const int two_pass) {
     typedef typename Vec<T>::v8 frag_t;
     constexpr int N = TN * 16;
     constexpr int W_ROWS = TPS * N, W_BYTES = W_ROWS * 128, W_ITERS = W_ROWS * 8 / 256;
@@ -175,6 +199,72 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the writes have landed before this wave reaches the barrier
     };
+    // UP, horizontal scale <= 0.9 (the patch's 34 columns then come from at most 32 source columns): separable form with a
+    // third of the global loads.  Pass 1 blends the two source rows of every halo row for the source columns the patch
+    // touches and parks the result in the first columns of that halo row; pass 2 reads two parked columns per piece, and
+    // after a barrier (the expansion is in place) writes the final piece.  The parked values are rounded to T, so a halo
+    // value carries two roundings here instead of one.
+    auto blend_halo_2pass = [&](int cc) {
+        const unsigned px_step = p.cin * sizeof(T), row_step = src_w * px_step;
+        const char* a_cc = reinterpret_cast<const char*>(a_img) + cc * 128;
+        const int xs0 = (int)(up_sx * (float)max(ox0 - 1, 0));                          // first source column of the patch
+        const int xs_last = min((int)(up_sx * (float)min(ox0 + PT_W, p.in_w - 1)) + 1, src_w - 1);
+        const int ncol = xs_last - xs0 + 1;                                           // <= 32
+        {
+            const int c = tid >> 3, chunk = tid & 7;
+            const bool col_ok = c < ncol;
+            const unsigned col_off = (unsigned)(xs0 + (col_ok ? c : 0)) * px_step + (chunk << 4);
+            constexpr int RG = TN >= 8 ? 2 : TN >= 4 ? 5 : 10;                                   // halo rows whose loads fly together
+#pragma unroll 1
+            for (int r0 = 0; r0 < HALO_H; r0 += RG) {
+                u32x4 top[RG], bot[RG];
+                float wy[RG];
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const int iy = min(max(oy0 + r0 + r - 1, 0), p.in_h - 1);         // rows outside the image: any row
+                    const float fy = up_sy * (float)iy;
+                    const int y0 = (int)fy;
+                    wy[r] = fy - (float)y0;
+                    const unsigned o0 = (unsigned)y0 * row_step + col_off;
+                    top[r] = *reinterpret_cast<const u32x4*>(a_cc + o0);
+                    bot[r] = *reinterpret_cast<const u32x4*>(a_cc + (o0 + (y0 < src_h - 1 ? row_step : 0)));
+                }
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const int hpv = (r0 + r) * HALO_W + c;
+                    const u32x4 v = blend2<T>(top[r], bot[r], 1.f - wy[r], wy[r]);
+                    if (col_ok) *reinterpret_cast<u32x4*>(halo + hpv * 128 + ((chunk ^ (hpv & 7)) << 4)) = v;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        u32x4 res[HALO_ITERS];
+#pragma unroll
+        for (int it = 0; it < HALO_ITERS; ++it) {
+            const int piece = it * 256 + tid;
+            const int hp = piece >> 3, chunk = (piece & 7) ^ (hp & 7);
+            const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+            const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+            const bool ok = hp < HALO_PX && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
+            const float fx = up_sx * (float)(ok ? ix : 0);
+            const int x0 = (int)fx;
+            const float wx = fx - (float)x0;
+            const int row = (ok ? hy : 0) * HALO_W;
+            const int h0 = row + max(x0 - xs0, 0), h1 = row + max(min(x0 + 1, src_w - 1) - xs0, 0);
+            const u32x4 a = *reinterpret_cast<const u32x4*>(halo + h0 * 128 + ((chunk ^ (h0 & 7)) << 4));
+            const u32x4 b = *reinterpret_cast<const u32x4*>(halo + h1 * 128 + ((chunk ^ (h1 & 7)) << 4));
+            res[it] = blend2<T>(a, b, 1.f - wx, wx);
+            if (!ok) res[it] = u32x4{0u, 0u, 0u, 0u};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                                 // every parked value has been read
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < HALO_ITERS; ++it) *reinterpret_cast<u32x4*>(halo + (it * 256 + tid) * 16) = res[it];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
     auto issue_w = [&](int s, int buf) {
         const int cc = s / SPC, tap0 = (s - cc * SPC) * TPS;
         const bf16* wb = reinterpret_cast<const bf16*>(p.w) + ((size_t)n0 * 9 + tap0) * p.cin + cc * 64;
@@ -203,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     for (int s = 0; s < steps; ++s) {
         const int cc = s / SPC, tg = s - cc * SPC;
         if (tg == 0) {                                       // all reads of the previous slice ended at the last barrier
-            if (UP) blend_halo(cc); else issue_halo(cc);
+            if (UP) { if (two_pass) blend_halo_2pass(cc); else blend_halo(cc); } else issue_halo(cc);
         }
         if (s + 1 < steps) {
             issue_w(s + 1, (s + 1) & 1);
@@ -312,9 +402,12 @@ int launch_cfg(const VdaGemmArgs& a, hipStream_t s) {
     const int tiles_x = (a.out_w + PT_W - 1) / PT_W, tiles_y = (a.out_h + PT_H - 1) / PT_H;
     const int imgs = a.M / (a.out_h * a.out_w);
     const int lds = HALO_BYTES + 2 * TPS * TN * 16 * 128;
+    // the separable resampling needs the 34 halo columns to come from at most 32 source columns; its second rounding is
+    // 2^-12 relative in fp16 but 2^-9 in bf16, where the four-tap form is kept
+    const int two_pass = UP && sizeof(T) == 2 && a.ab_type == VDA_T_F16 && 10L * (a.up_w - 1) <= 9L * (a.in_w - 1);
     auto k = conv3_direct_kernel<TN, TPS, RELU_IN, UP, T>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)(imgs * tiles_x * tiles_y), a.N / (TN * 16)), dim3(256), lds, s, a, tiles_x, tiles_y);
+    hipLaunchKernelGGL(k, dim3((unsigned)(imgs * tiles_x * tiles_y), a.N / (TN * 16)), dim3(256), lds, s, a, tiles_x, tiles_y, two_pass);
     return hip_rc(hipGetLastError());
 }
 
