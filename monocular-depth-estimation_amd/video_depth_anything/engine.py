@@ -105,10 +105,10 @@ class Engine:
             hip.layernorm(xs, y, b["ln1_w"], b["ln1_b"], M, D, 1e-6)
             self.linear(y, b["wqkv"], qkv, b["bqkv"])
             hip.attention(qkv, att, frames, N, heads)
-            self.linear(att, b["wproj"], xs, b["bproj"], gamma=b["ls1"], resid=xs, ldr=D)
+            self.linear(att, b["wproj"], xs, b["bproj"], resid=xs, ldr=D)         # LayerScale is folded into the weights
             hip.layernorm(xs, y, b["ln2_w"], b["ln2_b"], M, D, 1e-6)
             self.linear(y, b["wfc1"], hid, b["bfc1"], act=hip.ACT_GELU)
-            self.linear(hid, b["wfc2"], xs, b["bfc2"], gamma=b["ls2"], resid=xs, ldr=D)
+            self.linear(hid, b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D)
             if i in w.taps:
                 t = _empty((frames * hw, D), self.hdt, dev)
                 hip.layernorm(xs, t, w.norm_w, w.norm_b, frames * hw, D, 1e-6, rows_per_group=hw, in_group=N, in_skip=1)

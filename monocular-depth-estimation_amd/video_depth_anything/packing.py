@@ -131,13 +131,17 @@ class PackedWeights:
             wqkv, bqkv = g(b + "attn.qkv.weight").clone(), g(b + "attn.qkv.bias").clone()
             wqkv[:D] *= 0.125
             bqkv[:D] *= 0.125
+            # LayerScale (layer_scale.py:27-28) is folded into the projection it follows: gamma * (x W^T + b) =
+            # x (gamma W)^T + gamma b, rounded to the operand type once, from the fp32 product.  The residual GEMMs then
+            # have a plain "+ bias + residual" epilogue, whose residual read the kernel hides in its K loop.
+            ls1, ls2 = g(b + "ls1.gamma"), g(b + "ls2.gamma")
             self.blocks.append(dict(
                 ln1_w=f32(g(b + "norm1.weight")), ln1_b=f32(g(b + "norm1.bias")),
                 wqkv=bf(wqkv), bqkv=f32(bqkv),
-                wproj=bf(g(b + "attn.proj.weight")), bproj=f32(g(b + "attn.proj.bias")), ls1=f32(g(b + "ls1.gamma")),
+                wproj=bf(ls1[:, None] * g(b + "attn.proj.weight")), bproj=f32(ls1 * g(b + "attn.proj.bias")),
                 ln2_w=f32(g(b + "norm2.weight")), ln2_b=f32(g(b + "norm2.bias")),
                 wfc1=bf(g(b + "mlp.fc1.weight")), bfc1=f32(g(b + "mlp.fc1.bias")),
-                wfc2=bf(g(b + "mlp.fc2.weight")), bfc2=f32(g(b + "mlp.fc2.bias")), ls2=f32(g(b + "ls2.gamma")),
+                wfc2=bf(ls2[:, None] * g(b + "mlp.fc2.weight")), bfc2=f32(ls2 * g(b + "mlp.fc2.bias")),
             ))
 
         h = "head."

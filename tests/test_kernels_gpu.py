@@ -59,6 +59,25 @@ def test_gemm_plain_exact_integers(M, N, K, cfg):
     assert torch.equal(out, want)
 
 
+@pytest.mark.parametrize("M,N,K,ldr", [(1370, 1024, 1024, 1024), (700, 256, 4096, 256), (256, 512, 1024, 640), (3, 256, 1536, 256)])
+def test_gemm_residual_added_inside_the_k_loop_exact_integers(M, N, K, ldr):
+    """fp32 residual + bias on the 256x256 tile (K >= 1024, N % 256 == 0): the residual blocks travel through LDS during the
+    first nine K-tiles.  Integer data makes the expected result exact; rows cut by M and a strided residual included."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).to(BF).to(DEV)
+    w = torch.randint(-3, 4, (N, K), generator=g).to(BF).to(DEV)
+    bias = torch.randint(-8, 9, (N,), generator=g).float().to(DEV)
+    resid = torch.randint(-1000, 1001, (M, ldr), generator=g).float().to(DEV)
+    want = a.float() @ w.float().t() + bias + resid[:, :N]
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, resid=resid, ldr=ldr, tile_cfg=2)
+    assert torch.equal(out, want)
+    if ldr == N:                                                        # in place, as the encoder's residual stream is updated
+        x = resid.clone()
+        hip.gemm(a, w, x, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, resid=x, ldr=N, tile_cfg=2)
+        assert torch.equal(x, want)
+
+
 @pytest.mark.parametrize("cfg", TILE_CFGS)
 @pytest.mark.parametrize("M,N,K", [(1370, 1024, 1024), (999, 384, 1536)])
 def test_gemm_epilogue_bias_gelu_gamma_residual(M, N, K, cfg):
@@ -72,6 +91,9 @@ def test_gemm_epilogue_bias_gelu_gamma_residual(M, N, K, cfg):
     x = resid.clone()
     hip.gemm(a, w, x, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, gamma=gamma, resid=x, ldr=N, tile_cfg=cfg)     # in place on the residual
     close(x, resid + gamma * acc, F32_OUT, "layerscale residual")
+    x = resid.clone()      # no gamma: on the 256x256 tile with K >= 1024 and N % 256 == 0 the residual is added inside the K loop
+    hip.gemm(a, w, x, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, resid=x, ldr=N, tile_cfg=cfg)
+    close(x, resid + acc, F32_OUT, "plain residual")
     r16, r2 = rnd((M, N), 6), rnd((M, N), 7)
     hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, act=hip.ACT_RELU, resid=r16, ldr=N, resid2=r2, ldr2=N, tile_cfg=cfg)
     close(out, F.relu(acc) + r16.float() + r2.float(), BF_OUT, "relu + 2 residuals")

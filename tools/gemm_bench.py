@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(ROOT, "monocular-depth-estimation_amd"))
 from video_depth_anything import hip
 cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3,4").split(",")]
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 43840
-# NxK or NxKxR; R = 1: the encoder's residual form, fp32 output updated in place with gamma * (acc + bias) + residual
+# NxK or NxKxR; R = 1: fp32 output updated in place with gamma * (acc + bias) + residual; R = 2: the same without gamma
+# (the encoder's form, LayerScale folded into the weights)
 shapes = [tuple(int(v) for v in x.split("x")) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [(3072, 1024), (1024, 1024, 1), (4096, 1024), (1024, 4096, 1)]
 shapes = [(s + (0,))[:3] for s in shapes]
 dev = "cuda"
@@ -15,7 +16,7 @@ for N, K, R in shapes:
     bias = torch.randn(N, device=dev)
     if R:
         x0 = torch.randn(M, N, device=dev); out = x0.clone(); gamma = torch.rand(N, device=dev) * 1e-3
-        kw = dict(bias=bias, gamma=gamma, resid=out, ldr=N)
+        kw = dict(bias=bias, gamma=gamma, resid=out, ldr=N) if R == 1 else dict(bias=bias, resid=out, ldr=N)
     else:
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16); kw = dict(bias=bias)
     ref = None
