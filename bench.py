@@ -142,14 +142,14 @@ def pmc_traffic(kernel_substring):
     """HBM-side bytes per launch of the dominant kernel on the flagship workload, from the committed counter passes
     (`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` over this same command, one pass each; FETCH_SIZE doubled for
     gfx950's 64-byte tally of 128-byte requests): counters cannot be collected from inside the timed process."""
-    path = os.path.join(ROOT, "profiles", "r1_step3_vitl518_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_step4_vitl518_hbm_traffic.json")
     try:
         rows = json.load(open(path))
         row = next(r for r in rows if kernel_substring in r["kernel"])
     except (OSError, StopIteration, ValueError):
         return {}
     return {"traffic": round(row["hbm_bytes_per_launch"]), "traffic_unit": "bytes per launch (fetch x2 + write)",
-            "traffic_source": "profiles/r1_step3_vitl518_hbm_traffic.json"}
+            "traffic_source": "profiles/r1_step4_vitl518_hbm_traffic.json"}
 
 
 def end_to_end(model, H, W, n=98):

@@ -25,19 +25,6 @@
 //   * both hold for the staggered halves because all distances above are counted in whole phases (two intervals) and the
 //     stagger is one interval.
 // In the last two K-tiles, phases that have nothing left to issue wait with vmcnt(0) instead.
-//
-// Residual in the loop (RES).  out = A W^T + bias + resid with an fp32 resid (the encoder's residual stream, usually
-// aliasing out) costs a 256 KB read per tile; in the epilogue that read runs at what one CU draws from HBM and nothing
-// overlaps it.  The RES variant instead copies the residual block of accumulator row i (16 rows x 64 columns of a wave,
-// 4 KiB, four global_load_lds per lane, whole 256-byte row segments) into a wave-private LDS area in phase P4 of K-tile
-// i, i = 0..7, and adds it to the accumulators in P4 of K-tile i+1: the read hides under the K loop, costs no registers,
-// and the epilogue is a plain store.  The 32 KiB of areas bring the kernel to the full 160 KiB of LDS.  These copies are
-// counted by vmcnt like the operand copies and retire in issue order between the copies of P4(i) and P1(i+1): while they
-// are among the five most recent groups the counted waits allow 12 instead of 8 operations in flight, and the wait of
-// P4(i+1), taken before the next group is issued, is again 8 -- the four regions issued since -- which also proves that
-// this wave's residual block has landed (the area is wave-private, so no barrier is involved).  16-byte chunk c of row r
-// sits at slot c ^ r of the row, which makes the fragment-shaped reads (16 rows, one chunk) conflict-free.  Needs
-// K >= 1024: the nine K-tiles involved are then never among the last two.
 #include "gemm_common.h"
 
 namespace vda {
@@ -49,14 +36,13 @@ constexpr int REGION = 16384;
 constexpr int R_A0 = 0, R_B0 = 1, R_B1 = 2, R_A1 = 3;
 
 __device__ __forceinline__ void wait_vm8() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-__device__ __forceinline__ void wait_vm12() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void phase_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
 
-template <int AMODE, bool RELU_IN, bool RES, typename T>
+template <int AMODE, bool RELU_IN, typename T>
 __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const GemmTiles gt) {
     typedef typename Vec<T>::v8 frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -190,103 +176,55 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const
     phase_barrier();
     if (group1) phase_barrier();
 
-    // residual copies: instruction k of a block covers rows 4k .. 4k+3, lane l -> row 4k + l/16, slot l%16 (lane-linear),
-    // which must hold chunk slot ^ row; rows past M re-read row M-1 (those accumulator rows are never stored)
-    char* res_area = smem + 8 * REGION + wave * 4096;
-    const char* res_base = reinterpret_cast<const char*>(p.resid) + ((size_t)(m0 + wm * 128) * p.ldr + n0 + wn * 64) * 4;   // wave-uniform
-    const int res_m_room = p.M - 1 - (m0 + wm * 128);                // rows of this wave's block that exist, minus one
-
     for (int t = 0; t < nk; ++t) {
-        const bool res_flying = RES && t >= 1 && t <= 8;             // the residual loads of K-tile t-1 are in flight
         const int cur = t & 1;
         const char* buf = smem + cur * (4 * REGION);
         const bool next1 = t + 1 < nk, next2 = t + 2 < nk;
         // P1
         read_a(buf + R_A0 * REGION);
         read_b(buf + R_B0 * REGION, bf0);
-        if (next1) { issue_b(1, t + 1, cur ^ 1); if (res_flying) wait_vm12(); else wait_vm8(); } else { wait_vm0(); }
+        if (next1) { issue_b(1, t + 1, cur ^ 1); wait_vm8(); } else { wait_vm0(); }
         phase_barrier();
         quadrant(0, 0, bf0);
         phase_barrier();
         // P2
         read_b(buf + R_B1 * REGION, bf1);
-        if (next1) { issue_a(1, t + 1, cur ^ 1); if (res_flying) wait_vm12(); else wait_vm8(); } else { wait_vm0(); }
+        if (next1) { issue_a(1, t + 1, cur ^ 1); wait_vm8(); } else { wait_vm0(); }
         phase_barrier();
         quadrant(0, 1, bf1);
         phase_barrier();
         // P3
         read_a(buf + R_A1 * REGION);
-        if (next2) { issue_a(0, t + 2, cur); if (res_flying) wait_vm12(); else wait_vm8(); } else { wait_vm0(); }
+        if (next2) { issue_a(0, t + 2, cur); wait_vm8(); } else { wait_vm0(); }
         phase_barrier();
         quadrant(1, 1, bf1);
         phase_barrier();
         // P4
         if (next2) { issue_b(0, t + 2, cur); wait_vm8(); } else { wait_vm0(); }
-        if (RES && t <= 8) {                                         // K >= 1024: none of these is one of the last two K-tiles
-            if (t >= 1) {
-                f32x4 r[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    r[j] = *reinterpret_cast<const f32x4*>(res_area + frow * 256 + (((j * 4 + fq) ^ frow) << 4));
-                // branch-free: every accumulator row takes the block times 1 (its turn) or 0; a switch over t made the
-                // register allocator copy accumulators around and spill
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (t == i + 1) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j] += r[j];
-                    }
-                }
-            }
-            if (t <= 7) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int rb = 4 * k + (lane >> 4);                                // row inside the 16-row block
-                    // (negative for a wave whose whole block lies past M: back to row M-1)
-                    const int off = min(t * 16 + rb, res_m_room) * (p.ldr * 4) + (((lane & 15) ^ rb) << 4);
-                    glds16(res_base + (ptrdiff_t)off, res_area + k * 1024);
-                }
-            }
-        }
         phase_barrier();
         quadrant(1, 0, bf0);
         phase_barrier();
     }
     if (!group1) phase_barrier();     // every wave executes the same number of barriers
 
-    if (RES) {
-        VdaGemmArgs q = p;                                         // the residual is already in the accumulators
-        q.resid = nullptr;
-        q.resid_type = VDA_T_NONE;
-        gemm_epilogue<8, 4>(q, acc, m0 + wm * 128 + frow, n0 + wn * 64 + fq * 4, fq, smem + wave * STAGE_BYTES);
-    } else {
-        gemm_epilogue<8, 4>(p, acc, m0 + wm * 128 + frow, n0 + wn * 64 + fq * 4, fq, smem + wave * STAGE_BYTES);
-    }
+    gemm_epilogue<8, 4>(p, acc, m0 + wm * 128 + frow, n0 + wn * 64 + fq * 4, fq, smem + wave * STAGE_BYTES);
 }
 
 template <typename T>
 int launch_t(const VdaGemmArgs& a, hipStream_t s) {
     GemmTiles gt{(a.M + 255) / 256, (a.N + 255) / 256};
+    const int lds = 8 * REGION;
     dim3 grid(gt.tiles_m * gt.tiles_n);
-#define VDA_LAUNCH256(MODE, RELU, RES)                                                                               \
+#define VDA_LAUNCH256(MODE, RELU)                                                                                    \
     do {                                                                                                             \
-        auto k = gemm256_kernel<MODE, RELU, RES, T>;                                                                 \
-        const int lds = 8 * REGION + (RES ? 8 * 4096 : 0);                                                           \
+        auto k = gemm256_kernel<MODE, RELU, T>;                                                                      \
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
         hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a, gt);                                                       \
     } while (0)
-    // the residual can ride in the K loop when it is the only extra term of a plain fp32 epilogue and no column tile is
-    // ragged.  Measured at M = 43840, N = 1024: K = 1024 158 -> 133 us, K = 4096 404 -> 410 us (over a long K loop the CUs
-    // drift apart and their epilogue reads already overlap other CUs' loops), hence only for short K.
-    const bool res_in_loop = a.a_mode == VDA_A_LINEAR && !a.relu_in && a.epi == VDA_EPI_PLAIN && a.resid_type == VDA_T_F32 &&
-                             !a.resid2 && !a.gamma && a.act == VDA_ACT_NONE && a.K >= 1024 && a.K <= 2048 && a.N % 256 == 0 &&
-                             ((uintptr_t)a.resid & 15) == 0 && a.ldr < (1 << 20);
     if (a.a_mode == VDA_A_CONV3) {
-        if (a.relu_in) VDA_LAUNCH256(VDA_A_CONV3, true, false); else VDA_LAUNCH256(VDA_A_CONV3, false, false);
-    } else if (res_in_loop) {
-        VDA_LAUNCH256(VDA_A_LINEAR, false, true);
+        if (a.relu_in) VDA_LAUNCH256(VDA_A_CONV3, true); else VDA_LAUNCH256(VDA_A_CONV3, false);
     } else {
-        if (a.relu_in) VDA_LAUNCH256(VDA_A_LINEAR, true, false); else VDA_LAUNCH256(VDA_A_LINEAR, false, false);
+        if (a.relu_in) VDA_LAUNCH256(VDA_A_LINEAR, true); else VDA_LAUNCH256(VDA_A_LINEAR, false);
     }
 #undef VDA_LAUNCH256
     return hip_rc(hipGetLastError());

@@ -133,7 +133,7 @@ class PackedWeights:
             bqkv[:D] *= 0.125
             # LayerScale (layer_scale.py:27-28) is folded into the projection it follows: gamma * (x W^T + b) =
             # x (gamma W)^T + gamma b, rounded to the operand type once, from the fp32 product.  The residual GEMMs then
-            # have a plain "+ bias + residual" epilogue, whose residual read the kernel hides in its K loop.
+            # have a plain "+ bias + residual" epilogue.
             ls1, ls2 = g(b + "ls1.gamma"), g(b + "ls2.gamma")
             self.blocks.append(dict(
                 ln1_w=f32(g(b + "norm1.weight")), ln1_b=f32(g(b + "norm1.bias")),

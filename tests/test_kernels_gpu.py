@@ -60,9 +60,9 @@ def test_gemm_plain_exact_integers(M, N, K, cfg):
 
 
 @pytest.mark.parametrize("M,N,K,ldr", [(1370, 1024, 1024, 1024), (700, 256, 4096, 256), (256, 512, 1024, 640), (3, 256, 1536, 256)])
-def test_gemm_residual_added_inside_the_k_loop_exact_integers(M, N, K, ldr):
-    """fp32 residual + bias on the 256x256 tile (K >= 1024, N % 256 == 0): the residual blocks travel through LDS during the
-    first nine K-tiles.  Integer data makes the expected result exact; rows cut by M and a strided residual included."""
+def test_gemm_fp32_residual_on_the_large_tile_exact_integers(M, N, K, ldr):
+    """fp32 residual + bias on the 256x256 tile, the form of the encoder's residual updates (LayerScale is folded into the
+    weights).  Integer data makes the expected result exact; rows cut by M and a strided residual included."""
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randint(-3, 4, (M, K), generator=g).to(BF).to(DEV)
     w = torch.randint(-3, 4, (N, K), generator=g).to(BF).to(DEV)
@@ -91,7 +91,7 @@ def test_gemm_epilogue_bias_gelu_gamma_residual(M, N, K, cfg):
     x = resid.clone()
     hip.gemm(a, w, x, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, gamma=gamma, resid=x, ldr=N, tile_cfg=cfg)     # in place on the residual
     close(x, resid + gamma * acc, F32_OUT, "layerscale residual")
-    x = resid.clone()      # no gamma: on the 256x256 tile with K >= 1024 and N % 256 == 0 the residual is added inside the K loop
+    x = resid.clone()      # no gamma: the encoder's residual update once LayerScale is folded into the weights
     hip.gemm(a, w, x, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, resid=x, ldr=N, tile_cfg=cfg)
     close(x, resid + acc, F32_OUT, "plain residual")
     r16, r2 = rnd((M, N), 6), rnd((M, N), 7)
