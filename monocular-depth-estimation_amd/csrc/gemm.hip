@@ -207,7 +207,9 @@ extern "C" int vda_gemm(const VdaGemmArgs* args, void* stream) {
     // (measured at M = 43840: K = 4096 1208 vs 870 TFLOP/s, K = 1024 835-953 vs 770-821; whole model +6.7 %).
     const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     // (with a long K loop one partly filled round of large tiles still beats the small tile: K = 9216, 172-184 tiles)
-    const bool fills = tiles256 >= 192 || (a.K >= 4096 && tiles256 >= 160);
+    // (and the column tiles must not be mostly padding: N = 384 wastes a quarter of two 256-wide tiles; 128x128 tiles then
+    // win, 96 vs 105 us at M = 43840, K = 1536)
+    const bool fills = (tiles256 >= 192 || (a.K >= 4096 && tiles256 >= 160)) && 5 * a.N >= 4 * 256 * ((a.N + 255) / 256);
     const bool big = a.tile_cfg == 2 || (a.tile_cfg == 0 && a.N >= 192 && a.K >= 1024 && fills);
     if (big) return launch_gemm256(a, s);
     return launch<128, 128, 2, 2>(a, s);
