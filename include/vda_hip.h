@@ -50,12 +50,14 @@ const char* vda_version(void);
  *   motion_module/attention.py:81-83,90 (via motion_module.py:242-250,290), attention.py:333,374,383-384.
  * ------------------------------------------------------------------------------------------------------------- */
 enum { VDA_A_LINEAR = 0, VDA_A_CONV3 = 1 };
-enum { VDA_ACT_NONE = 0, VDA_ACT_GELU = 1, VDA_ACT_RELU = 2 };          /* GELU is the exact erf form            */
+enum { VDA_ACT_NONE = 0, VDA_ACT_GELU = 1, VDA_ACT_RELU = 2 };          /* GELU: the erf form, evaluated to 5.4e-5
+                                                                           absolute (a fit of erf; 16-bit out_type only) */
 enum { VDA_T_NONE = 0, VDA_T_F32 = 1, VDA_T_BF16 = 2, VDA_T_F16 = 3 };   /* "half" below = BF16 or F16 (IEEE half)  */
 enum {
     VDA_EPI_PLAIN = 0,
     VDA_EPI_GEGLU = 1,  /* W rows interleaved in blocks of 16: [val 0..15, gate 0..15, val 16..31, ...]; out has N/2
-                           columns: out = (val + b) * gelu(gate + b)   (motion_module/attention.py:382-384)        */
+                           columns: out = (val + b) * gelu(gate + b)   (motion_module/attention.py:382-384);
+                           16-bit out_type only, like VDA_ACT_GELU                                                  */
     VDA_EPI_CONVT = 2,  /* ConvTranspose2d with kernel == stride == ct_k: row m = input pixel (img, y, x) of an
                            [*, ct_h, ct_w] grid, n = (ky*ct_k + kx)*ct_c + co; the value lands at output pixel
                            (img, y*ct_k+ky, x*ct_k+kx), channel co of an NHWC image with ct_c channels (dpt.py:71-82) */
@@ -148,13 +150,20 @@ int vda_im2col_patch14(const float* x, void* out, int frames, int H, int W, int 
 int vda_assemble_tokens(const float* tok, const float* cls, const float* pos, float* x, int frames, int hw, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * fp32 mode operand split: x fp32 [rows][ldx] (first C columns used, C % 4 == 0) -> out bf16 [rows][3*Cp], segments
- * [hi | lo | hi] of Cp columns each (Cp % 64 == 0, columns C..Cp-1 zero), hi = bf16(v), lo = bf16(v - hi); relu != 0
- * applies max(v, 0) first (the pre-activation of util/blocks.py:78, which cannot be applied to hi and lo separately).
+ * fp32 mode operand split: x fp32 [rows][ldx] -> out bf16 [rows][3*Cp], segments [hi | lo | hi] of Cp columns each
+ * (Cp % 64 == 0, columns C..Cp-1 zero, C % 4 == 0), hi = bf16(v), lo = bf16(v - hi).  `act` is applied to v first, because
+ * an activation cannot be applied to hi and lo separately:
+ *   VDA_SPLIT_RELU   max(v, 0): the pre-activation of util/blocks.py:78;
+ *   VDA_SPLIT_GELU   exact-form GELU (mlp.py:37): in the fp32 mode fc1 stores its pre-activation and fc2's operand is
+ *                    split here (vda_gemm's own GELU is accurate to 16-bit storage only);
+ *   VDA_SPLIT_GEGLU  the input row holds 2C values in blocks [16 values | 16 gates] (the column order of a GEGLU
+ *                    projection packed for VDA_EPI_GEGLU, run with a plain epilogue); v = value * GELU(gate)
+ *                    (motion_module/attention.py:382-384); C % 16 == 0, ldx >= 2C.
  * For an NHWC image rows = pixels and the result is an image with 3*Cp channels: the CONV3 operand for weights packed
  * [Cout][9][hi | hi | lo].  No counterpart in the reference (its fp32 path multiplies in fp32).
  * ------------------------------------------------------------------------------------------------------------- */
-int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int relu, void* stream);
+enum { VDA_SPLIT_NONE = 0, VDA_SPLIT_RELU = 1, VDA_SPLIT_GELU = 2, VDA_SPLIT_GEGLU = 3 };
+int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int act, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Frame preprocessing: uint8 RGB frames [frames][h0][w0][3] -> fp32 [frames][3][H][W]: x/255, bicubic resize with

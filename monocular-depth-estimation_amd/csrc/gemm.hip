@@ -185,6 +185,8 @@ extern "C" int vda_gemm(const VdaGemmArgs* args, void* stream) {
         return VDA_EINVAL;
     }
     if (a.out_type != VDA_T_F32 && a.out_type != VDA_T_BF16 && a.out_type != VDA_T_F16) return VDA_EINVAL;
+    // the epilogue's GELU is accurate to 16-bit storage only; fp32 callers apply the exact one in vda_split3
+    if ((a.act == VDA_ACT_GELU || a.epi == VDA_EPI_GEGLU) && a.out_type == VDA_T_F32) return VDA_ESHAPE;
     if (a.ab_type != VDA_T_BF16 && a.ab_type != VDA_T_F16) return VDA_EINVAL;
     if (a.tile_cfg < 0 || a.tile_cfg > 3) return VDA_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -116,7 +116,11 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
             for (int j = 0; j < TN; j += 2) {
                 f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (acc[i][j][r] + bias[j][r]) * gelu_erf(acc[i][j + 1][r] + bias[j + 1][r]);
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j + 1][r] + bias[j + 1][r];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= acc[i][j][r] + bias[j][r];
                 store4(srow, p.out_type, (j / 2) * 16 + fq * 4, v);
             }
         } else {
@@ -125,8 +129,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
                 const int n = ncol0 + j * 16;
                 f32x4 v = acc[i][j] + bias[j];
                 if (p.act == VDA_ACT_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
                 } else if (p.act == VDA_ACT_RELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -218,7 +222,11 @@ __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)
                 if (m >= p.M) continue;
                 f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (acc[i][j][r] + bv[r]) * gelu_erf(acc[i][j + 1][r] + bg[r]);
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j + 1][r] + bg[r];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= acc[i][j][r] + bv[r];
                 store4(p.out, p.out_type, (size_t)m * p.ldc + oc, v);
             }
         }
@@ -247,7 +255,7 @@ __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)
             f32x4 v = acc[i][j] + b;
             if (p.act == VDA_ACT_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
             } else if (p.act == VDA_ACT_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);

@@ -163,9 +163,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
 
 // fp32 rows -> bf16 rows of three segments [hi | lo | hi] (each Cp wide, zero beyond C): the A operand of a GEMM whose
 // weight rows are packed [hi | hi | lo], so that one bf16 MFMA pass over K' = 3 Cp accumulates hi*hi + lo*hi + hi*lo.
+// An activation is applied first (it cannot be applied to hi and lo separately); for VDA_SPLIT_GEGLU the input row holds
+// 2C values in blocks [16 values | 16 gates] and output column c is value * GELU(gate).
 // One workgroup per 4 rows; 32-bit index arithmetic inside a row.
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, bf16* __restrict__ out, long rows, int C,
-                                                     int ldx, int Cp, int relu) {
+                                                     int ldx, int Cp, int act) {
     const long row0 = (long)blockIdx.x * 4;
     const int cv = Cp / 4;
     for (int i = threadIdx.x; i < 4 * cv; i += 256) {
@@ -173,12 +175,23 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
         const long row = row0 + r;
         if (row >= rows) break;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c < C) v = *reinterpret_cast<const f32x4*>(x + row * ldx + c);      // C % 4 == 0
+        if (c < C) {                                                              // C % 4 == 0
+            if (act == VDA_SPLIT_GEGLU) {
+                const float* s = x + row * ldx + (c >> 4) * 32 + (c & 15);
+                v = *reinterpret_cast<const f32x4*>(s);
+                const f32x4 g = *reinterpret_cast<const f32x4*>(s + 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] *= gelu_erf(g[k]);
+            } else {
+                v = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
+            }
+        }
         bf16x4 hi, lo;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float f = v[k];
-            if (relu) f = fmaxf(f, 0.f);
+            if (act == VDA_SPLIT_RELU) f = fmaxf(f, 0.f);
+            if (act == VDA_SPLIT_GELU) f = gelu_erf(f);
             bf16 h, l;
             split_bf16(f, h, l);
             hi[k] = h;
@@ -244,11 +257,14 @@ extern "C" int vda_im2col_patch14(const float* x, void* out, int frames, int H, 
     return hip_rc(hipGetLastError());
 }
 
-extern "C" int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int relu, void* stream) {
+extern "C" int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int act, void* stream) {
     if (!x || !out || rows <= 0 || C <= 0) return VDA_EINVAL;
-    if (C % 4 != 0 || Cp % 64 != 0 || Cp < C || ldx < C || ldx % 4 != 0 || (rows + 3) / 4 > 0x7fffffffL) return VDA_ESHAPE;
+    if (act < VDA_SPLIT_NONE || act > VDA_SPLIT_GEGLU) return VDA_EINVAL;
+    const int in_cols = act == VDA_SPLIT_GEGLU ? 2 * C : C;
+    if (C % 4 != 0 || Cp % 64 != 0 || Cp < C || ldx < in_cols || ldx % 4 != 0 || (rows + 3) / 4 > 0x7fffffffL) return VDA_ESHAPE;
+    if (act == VDA_SPLIT_GEGLU && C % 16 != 0) return VDA_ESHAPE;
     hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                       reinterpret_cast<bf16*>(out), rows, C, ldx, Cp, relu);
+                       reinterpret_cast<bf16*>(out), rows, C, ldx, Cp, act);
     return hip_rc(hipGetLastError());
 }
 

@@ -32,17 +32,21 @@ class Engine:
         self.edt = torch.float32 if self.split else BF16      # storage type of the encoder's GEMM operands
 
     # ---- small wrappers -------------------------------------------------------------------------------------------
-    def operand(self, a, relu=False):
-        """The MFMA operand of activation matrix ``a`` [rows, K]: itself, or its bf16 [hi | lo | hi] split in fp32 mode."""
+    def operand(self, a, relu=False, act=None):
+        """The MFMA operand of activation matrix ``a`` [rows, K]: itself, or its bf16 [hi | lo | hi] split in fp32 mode
+        (``act``: an activation the split applies first; GEGLU halves the width)."""
         if not self.split:
+            assert act is None
             return a, relu
         rows, K = a.shape
+        if act == hip.SPLIT_GEGLU:
+            K //= 2
         a3 = _empty((rows, 3 * K), BF16, self.dev)
-        hip.split3(a, a3, rows, K, a.stride(0), K, relu=relu)
+        hip.split3(a, a3, rows, K, a.stride(0), K, relu=relu, act=act)
         return a3, False
 
-    def linear(self, a, w, out, bias=None, **kw):
-        a, _ = self.operand(a)
+    def linear(self, a, w, out, bias=None, a_act=None, **kw):
+        a, _ = self.operand(a, act=a_act)
         M, K = a.shape[0], a.shape[-1]
         N = kw.pop("N", w.shape[0])
         hip.gemm(a, w, out, M=M, N=N, K=K, lda=a.stride(0), ldc=kw.pop("ldc", out.stride(0)), bias=bias, **kw)
@@ -107,8 +111,12 @@ class Engine:
             hip.attention(qkv, att, frames, N, heads)
             self.linear(att, b["wproj"], xs, b["bproj"], resid=xs, ldr=D)         # LayerScale is folded into the weights
             hip.layernorm(xs, y, b["ln2_w"], b["ln2_b"], M, D, 1e-6)
-            self.linear(y, b["wfc1"], hid, b["bfc1"], act=hip.ACT_GELU)
-            self.linear(hid, b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D)
+            if self.split:      # fp32 storage: fc1 stores its pre-activation, the exact GELU runs in fc2's operand split
+                self.linear(y, b["wfc1"], hid, b["bfc1"])
+                self.linear(hid, b["wfc2"], xs, b["bfc2"], a_act=hip.SPLIT_GELU, resid=xs, ldr=D)
+            else:
+                self.linear(y, b["wfc1"], hid, b["bfc1"], act=hip.ACT_GELU)
+                self.linear(hid, b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D)
             if i in w.taps:
                 t = _empty((frames * hw, D), self.hdt, dev)
                 hip.layernorm(xs, t, w.norm_w, w.norm_b, frames * hw, D, 1e-6, rows_per_group=hw, in_group=N, in_skip=1)
@@ -137,9 +145,14 @@ class Engine:
             hip.temporal_attention(qkv, o, B, T, hw, TEMPORAL_HEADS, hd, hd ** -0.5)
             self.linear(o, a["wo"], hs, a["bo"], resid=hs, ldr=C)
         hip.layernorm(hs, n, m["ffn_w"], m["ffn_b"], M, C, 1e-5)
-        ff = _empty((M, 4 * C), self.hdt, dev)
-        self.linear(n, m["ff1_w"], ff, m["ff1_b"], epi=hip.EPI_GEGLU)
-        self.linear(ff, m["ff2_w"], o, m["ff2_b"], resid=hs, ldr=C)          # bf16 out: only proj_out reads it
+        if self.split:          # fp32 storage: plain projection to [values | gates], the gated GELU runs in ff2's operand split
+            ff = _empty((M, 8 * C), self.hdt, dev)
+            self.linear(n, m["ff1_w"], ff, m["ff1_b"])
+            self.linear(ff, m["ff2_w"], o, m["ff2_b"], a_act=hip.SPLIT_GEGLU, resid=hs, ldr=C)
+        else:
+            ff = _empty((M, 4 * C), self.hdt, dev)
+            self.linear(n, m["ff1_w"], ff, m["ff1_b"], epi=hip.EPI_GEGLU)
+            self.linear(ff, m["ff2_w"], o, m["ff2_b"], resid=hs, ldr=C)      # 16-bit out: only proj_out reads it
         out = _empty((f, h, wd, C), self.hdt, dev)
         self.linear(o, m["out_w"], out.reshape(M, C), m["out_b"], resid=xf, ldr=C)
         return out

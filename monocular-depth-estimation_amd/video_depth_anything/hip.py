@@ -192,10 +192,16 @@ def attention(qkv, out, frames, n_tok, heads):
     _check(lib().vda_attention(_ptr(qkv), _ptr(out), frames, n_tok, heads, _type(qkv), _stream()), "vda_attention")
 
 
-def split3(x, out, rows, Cdim, ldx, Cp, relu=False):
-    """fp32 [rows][ldx] -> bf16 [rows][3*Cp] segments [hi | lo | hi] (the A operand of the fp32 mode's GEMMs)."""
+SPLIT_NONE, SPLIT_RELU, SPLIT_GELU, SPLIT_GEGLU = 0, 1, 2, 3
+
+
+def split3(x, out, rows, Cdim, ldx, Cp, relu=False, act=None):
+    """fp32 [rows][ldx] -> bf16 [rows][3*Cp] segments [hi | lo | hi] (the A operand of the fp32 mode's GEMMs), after the
+    activation ``act`` (SPLIT_*; ``relu=True`` is SPLIT_RELU)."""
     _dev(x, out)
-    _check(lib().vda_split3(_ptr(x), _ptr(out), rows, Cdim, ldx, Cp, int(bool(relu)), _stream()), "vda_split3")
+    if act is None:
+        act = SPLIT_RELU if relu else SPLIT_NONE
+    _check(lib().vda_split3(_ptr(x), _ptr(out), rows, Cdim, ldx, Cp, int(act), _stream()), "vda_split3")
 
 
 def layernorm(x, out, weight, bias, rows, Cdim, eps, rows_per_group=None, in_group=None, in_skip=0, pe=None, pe_hw=1, pe_T=1):

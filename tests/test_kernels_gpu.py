@@ -452,9 +452,45 @@ def test_gemm_fp32_mode_three_term_product(M, N, K, cfg):
     a3 = torch.empty((M, 3 * K), dtype=BF, device=DEV)
     hip.split3(a, a3, M, K, K, K)
     out = torch.empty((M, N), dtype=torch.float32, device=DEV)
-    hip.gemm(a3, split_w(w), out, M=M, N=N, K=3 * K, lda=3 * K, ldc=N, bias=bias, act=hip.ACT_GELU, tile_cfg=cfg)
-    want = F.gelu(a.double() @ w.double().t() + bias.double()).float()
+    hip.gemm(a3, split_w(w), out, M=M, N=N, K=3 * K, lda=3 * K, ldc=N, bias=bias, tile_cfg=cfg)
+    want = (a.double() @ w.double().t() + bias.double()).float()
     close(out, want, SPLIT_TOL, "three-term gemm")
+    with pytest.raises(RuntimeError):            # the epilogue's GELU is for 16-bit outputs; fp32 callers use vda_split3's
+        hip.gemm(a3, split_w(w), out, M=M, N=N, K=3 * K, lda=3 * K, ldc=N, bias=bias, act=hip.ACT_GELU, tile_cfg=cfg)
+
+
+def test_split3_gelu_and_geglu_are_exact_form():
+    """The activations the fp32 mode applies while splitting: erf-form GELU (mlp.py:37) and value * GELU(gate) on rows laid
+    out in blocks [16 values | 16 gates] (motion_module/attention.py:382-384), to fp32 accuracy."""
+    rows, C = 333, 192
+    x = rnd((rows, C), 1, 2.0, torch.float32)
+    out = torch.full((rows, 3 * C), float("nan"), dtype=BF, device=DEV)
+    hip.split3(x, out, rows, C, C, C, act=hip.SPLIT_GELU)
+    got = out[:, :C].float() + out[:, C:2 * C].float()
+    want = F.gelu(x.double()).float()
+    assert (got - want).abs().max() <= 2e-6 * want.abs().max() + 2.0 ** -16 * want.abs().max()
+    assert torch.equal(out[:, :C], out[:, 2 * C:])
+    xg = rnd((rows, 2 * C), 2, 2.0, torch.float32)
+    hip.split3(xg, out, rows, C, 2 * C, C, act=hip.SPLIT_GEGLU)
+    blocks = xg.reshape(rows, C // 16, 2, 16)
+    want = (blocks[:, :, 0].double() * F.gelu(blocks[:, :, 1].double())).reshape(rows, C).float()
+    got = out[:, :C].float() + out[:, C:2 * C].float()
+    assert (got - want).abs().max() <= 2e-6 * want.abs().max() + 2.0 ** -16 * want.abs().max()
+
+
+def test_gemm_gelu_polynomial_accuracy():
+    """The epilogue's GELU over the whole range that matters, through a one-hot product that passes the inputs unchanged:
+    against the erf form in fp64, within the stated 5.4e-5 absolute (before the 16-bit rounding of the output)."""
+    K = 64
+    xs = torch.linspace(-9.0, 9.0, 128 * K).reshape(128, K)                     # fp16 keeps these to 2^-11 relative
+    a = xs.to(torch.float16).to(DEV)
+    for c0 in range(0, K, 64):
+        w = torch.eye(K, dtype=torch.float16, device=DEV)
+        out = torch.empty((128, K), dtype=torch.float16, device=DEV)
+        hip.gemm(a, w, out, M=128, N=K, K=K, lda=K, ldc=K, act=hip.ACT_GELU)
+        want = F.gelu(a.double())
+        err = (out.double() - want).abs()
+        assert (err <= 5.4e-5 + 2.0 ** -11 * want.abs() + 1e-7).all(), err.max()
 
 
 def test_conv3x3_fp32_mode():
