@@ -69,9 +69,9 @@ __device__ __forceinline__ float gelu_poly(float x) {
 }
 // storage types: vectors of 4 / 8 elements per type (float: the fp32 storage mode)
 template <typename T> struct Vec;
-template <> struct Vec<bf16> { typedef bf16x4 v4; typedef bf16x8 v8; };
-template <> struct Vec<f16> { typedef f16x4 v4; typedef f16x8 v8; };
-template <> struct Vec<float> { typedef f32x4 v4; typedef f32x8 v8; };
+template <> struct Vec<bf16> { typedef bf16x4 v4; typedef bf16x8 v8; static constexpr bool is_bf16 = true; };
+template <> struct Vec<f16> { typedef f16x4 v4; typedef f16x8 v8; static constexpr bool is_bf16 = false; };
+template <> struct Vec<float> { typedef f32x4 v4; typedef f32x8 v8; static constexpr bool is_bf16 = false; };
 
 // hi/lo split of an fp32 value into two bf16: v = hi + lo up to 2^-17 |v|.  Three bf16 MFMA products
 // (hi*hi + lo*hi + hi*lo, fp32 accumulation) then reproduce an fp32 product to about 2^-16 relative.

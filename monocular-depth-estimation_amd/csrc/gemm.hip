@@ -12,7 +12,7 @@
 
 namespace vda {
 
-template <int BM, int BN, int WM, int WN, int AMODE, typename T>
+template <int BM, int BN, int WM, int WN, int AMODE, int SPEC, typename T>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const VdaGemmArgs p, const GemmTiles gt) {
     constexpr int TM = BM / WM / 16;      // 16x16 MFMA tiles per wave along M
     constexpr int TN = BN / WN / 16;
@@ -125,26 +125,35 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const VdaGemmArgs p,
         __syncthreads();   // also drains the in-flight copy of step kt+1 (vmcnt(0) precedes the barrier)
     }
 
-    gemm_epilogue<TM, TN>(p, acc, m0 + wm * (BM / WM) + frow, n0 + wn * (BN / WN) + fq * 4, fq, smem + wave * STAGE_BYTES);
+    gemm_epilogue_spec<SPEC, T, TM, TN>(p, acc, m0 + wm * (BM / WM) + frow, n0 + wn * (BN / WN) + fq * 4, fq, smem + wave * STAGE_BYTES);
 }
 
 namespace {
 
-template <int BM, int BN, int WM, int WN, typename T>
-int launch_t(const VdaGemmArgs& a, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int AMODE, int SPEC, typename T>
+int launch_k(const VdaGemmArgs& a, hipStream_t s) {
     GemmTiles gt{(a.M + BM - 1) / BM, (a.N + BN - 1) / BN};
     const int lds = 2 * (BM + BN) * 128;
     dim3 grid(gt.tiles_m * gt.tiles_n);
-    if (a.a_mode == VDA_A_CONV3) {
-        auto k = gemm_kernel<BM, BN, WM, WN, VDA_A_CONV3, T>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, s, a, gt);
-    } else {
-        auto k = gemm_kernel<BM, BN, WM, WN, VDA_A_LINEAR, T>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, s, a, gt);
-    }
+    auto k = gemm_kernel<BM, BN, WM, WN, AMODE, SPEC, T>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, s, a, gt);
     return hip_rc(hipGetLastError());
+}
+
+template <int BM, int BN, int WM, int WN, typename T>
+int launch_t(const VdaGemmArgs& a, hipStream_t s) {
+    if (a.a_mode == VDA_A_CONV3) return launch_k<BM, BN, WM, WN, VDA_A_CONV3, EPI_SPEC_GENERAL, T>(a, s);
+    if (BM == 128 && BN == 128) {           // the tile that carries the head's and ViT-S's linears: specialised epilogues
+        switch (epi_spec_of(a)) {
+#define VDA_CASE128(SPEC) case SPEC: return launch_k<BM, BN, WM, WN, VDA_A_LINEAR, (BM == 128 && BN == 128) ? SPEC : EPI_SPEC_GENERAL, T>(a, s);
+            VDA_CASE128(EPI_SPEC_OWN) VDA_CASE128(EPI_SPEC_OWN_GELU) VDA_CASE128(EPI_SPEC_F32_RES32) VDA_CASE128(EPI_SPEC_OWN_RES)
+            VDA_CASE128(EPI_SPEC_OWN_RES32) VDA_CASE128(EPI_SPEC_GEGLU) VDA_CASE128(EPI_SPEC_F32)
+#undef VDA_CASE128
+            default: break;
+        }
+    }
+    return launch_k<BM, BN, WM, WN, VDA_A_LINEAR, EPI_SPEC_GENERAL, T>(a, s);
 }
 
 template <int BM, int BN, int WM, int WN>

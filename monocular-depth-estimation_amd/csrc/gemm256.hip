@@ -42,7 +42,8 @@ __device__ __forceinline__ void phase_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int AMODE, bool RELU_IN, typename T>
+// SPEC: the epilogue specialisation (EPI_SPEC_*, gemm_common.h)
+template <int AMODE, bool RELU_IN, int SPEC, typename T>
 __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const GemmTiles gt) {
     typedef typename Vec<T>::v8 frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const
     }
     if (!group1) phase_barrier();     // every wave executes the same number of barriers
 
-    gemm_epilogue<8, 4>(p, acc, m0 + wm * 128 + frow, n0 + wn * 64 + fq * 4, fq, smem + wave * STAGE_BYTES);
+    gemm_epilogue_spec<SPEC, T, 8, 4>(p, acc, m0 + wm * 128 + frow, n0 + wn * 64 + fq * 4, fq, smem + wave * STAGE_BYTES);
 }
 
 template <typename T>
@@ -215,17 +216,38 @@ int launch_t(const VdaGemmArgs& a, hipStream_t s) {
     GemmTiles gt{(a.M + 255) / 256, (a.N + 255) / 256};
     const int lds = 8 * REGION;
     dim3 grid(gt.tiles_m * gt.tiles_n);
-#define VDA_LAUNCH256(MODE, RELU)                                                                                    \
+#define VDA_LAUNCH256(MODE, RELU, SPEC)                                                                              \
     do {                                                                                                             \
-        auto k = gemm256_kernel<MODE, RELU, T>;                                                                      \
+        auto k = gemm256_kernel<MODE, RELU, SPEC, T>;                                                                \
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
         hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a, gt);                                                       \
     } while (0)
-    if (a.a_mode == VDA_A_CONV3) {
-        if (a.relu_in) VDA_LAUNCH256(VDA_A_CONV3, true); else VDA_LAUNCH256(VDA_A_CONV3, false);
+    // specialised epilogues where the model spends its time; everything else takes the general one
+    const int spec = epi_spec_of(a);
+#define VDA_CASE256(MODE, RELU, SPEC) case SPEC: VDA_LAUNCH256(MODE, RELU, SPEC); break;
+    if (a.a_mode == VDA_A_CONV3 && a.relu_in) {
+        switch (spec) {
+            VDA_CASE256(VDA_A_CONV3, true, EPI_SPEC_OWN_RELU) VDA_CASE256(VDA_A_CONV3, true, EPI_SPEC_OWN_RES)
+            default: VDA_LAUNCH256(VDA_A_CONV3, true, EPI_SPEC_GENERAL);
+        }
+    } else if (a.a_mode == VDA_A_CONV3) {
+        switch (spec) {
+            VDA_CASE256(VDA_A_CONV3, false, EPI_SPEC_OWN) VDA_CASE256(VDA_A_CONV3, false, EPI_SPEC_OWN_RES)
+            VDA_CASE256(VDA_A_CONV3, false, EPI_SPEC_OWN_RES2)
+            default: VDA_LAUNCH256(VDA_A_CONV3, false, EPI_SPEC_GENERAL);
+        }
+    } else if (a.relu_in) {
+        VDA_LAUNCH256(VDA_A_LINEAR, true, EPI_SPEC_GENERAL);
     } else {
-        if (a.relu_in) VDA_LAUNCH256(VDA_A_LINEAR, true); else VDA_LAUNCH256(VDA_A_LINEAR, false);
+        switch (spec) {
+            VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN_GELU)
+            VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_F32_RES32) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN_RES)
+            VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN_RES32) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_GEGLU)
+            VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_F32)
+            default: VDA_LAUNCH256(VDA_A_LINEAR, false, EPI_SPEC_GENERAL);
+        }
     }
+#undef VDA_CASE256
 #undef VDA_LAUNCH256
     return hip_rc(hipGetLastError());
 }

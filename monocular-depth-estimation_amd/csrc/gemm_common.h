@@ -275,6 +275,64 @@ __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)
     }
 }
 
+// Epilogue specialisation.  The epilogue above decides everything at run time (output and residual types, activation,
+// LayerScale, epilogue kind); inlined into a kernel whose 128 accumulator registers leave little room, the code it does
+// not execute still costs (the encoder's 256x256 GEMMs ran 5 % slower with the general form).  A kernel instantiated with
+// SPEC > 0 calls the same function on a copy of its arguments whose choices are compile-time constants, so the compiler
+// drops every other branch.  "own" = the 16-bit type of the operands.
+enum {
+    EPI_SPEC_GENERAL = 0,
+    EPI_SPEC_OWN = 1,            // plain, own-type output, bias
+    EPI_SPEC_OWN_GELU = 2,       // ... with GELU
+    EPI_SPEC_F32_RES32 = 3,      // plain, fp32 output, bias + fp32 residual
+    EPI_SPEC_OWN_RES = 4,        // plain, own-type output, bias + own-type residual
+    EPI_SPEC_OWN_RES32 = 5,      // plain, own-type output, bias + fp32 residual
+    EPI_SPEC_GEGLU = 6,          // gated GELU, own-type output
+    EPI_SPEC_F32 = 7,            // plain, fp32 output, bias
+    EPI_SPEC_OWN_RELU = 8,       // plain, own-type output, bias, ReLU
+    EPI_SPEC_OWN_RES2 = 9,       // plain, own-type output, bias + two own-type residuals
+    EPI_SPEC_COUNT = 10
+};
+
+// the specialisation that describes this call exactly, or EPI_SPEC_GENERAL
+inline int epi_spec_of(const VdaGemmArgs& a) {
+    const int own = a.ab_type == VDA_T_F16 ? VDA_T_F16 : VDA_T_BF16;
+    if (a.gamma) return EPI_SPEC_GENERAL;
+    if (a.epi == VDA_EPI_GEGLU) return a.out_type == own ? EPI_SPEC_GEGLU : EPI_SPEC_GENERAL;
+    if (a.epi != VDA_EPI_PLAIN) return EPI_SPEC_GENERAL;
+    if (a.resid2) return a.out_type == own && a.resid_type == own && a.act == VDA_ACT_NONE ? EPI_SPEC_OWN_RES2 : EPI_SPEC_GENERAL;
+    if (a.out_type == own) {
+        if (a.resid_type == VDA_T_NONE)
+            return a.act == VDA_ACT_NONE ? EPI_SPEC_OWN : a.act == VDA_ACT_GELU ? EPI_SPEC_OWN_GELU : EPI_SPEC_OWN_RELU;
+        if (a.act != VDA_ACT_NONE) return EPI_SPEC_GENERAL;
+        return a.resid_type == own ? EPI_SPEC_OWN_RES : a.resid_type == VDA_T_F32 ? EPI_SPEC_OWN_RES32 : EPI_SPEC_GENERAL;
+    }
+    if (a.out_type == VDA_T_F32 && a.act == VDA_ACT_NONE) {
+        if (a.resid_type == VDA_T_NONE) return EPI_SPEC_F32;
+        if (a.resid_type == VDA_T_F32) return EPI_SPEC_F32_RES32;
+    }
+    return EPI_SPEC_GENERAL;
+}
+
+template <int SPEC, typename T, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_spec(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq, char* stage) {
+    if (SPEC == EPI_SPEC_GENERAL) {
+        gemm_epilogue<TM, TN>(p, acc, mrow0, ncol0, fq, stage);
+        return;
+    }
+    constexpr int own = Vec<T>::is_bf16 ? VDA_T_BF16 : VDA_T_F16;
+    VdaGemmArgs q = p;
+    q.gamma = nullptr;
+    q.epi = SPEC == EPI_SPEC_GEGLU ? VDA_EPI_GEGLU : VDA_EPI_PLAIN;
+    q.act = SPEC == EPI_SPEC_OWN_GELU ? VDA_ACT_GELU : SPEC == EPI_SPEC_OWN_RELU ? VDA_ACT_RELU : VDA_ACT_NONE;
+    q.out_type = (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_F32) ? VDA_T_F32 : own;
+    q.resid_type = (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_OWN_RES32) ? VDA_T_F32
+                   : (SPEC == EPI_SPEC_OWN_RES || SPEC == EPI_SPEC_OWN_RES2) ? own : VDA_T_NONE;
+    if (q.resid_type == VDA_T_NONE) q.resid = nullptr;
+    if (SPEC != EPI_SPEC_OWN_RES2) q.resid2 = nullptr;
+    gemm_epilogue<TM, TN>(q, acc, mrow0, ncol0, fq, stage);
+}
+
 // 256x256-tile kernel with the 4-phase software pipeline (gemm256.hip)
 int launch_gemm256(const VdaGemmArgs& a, hipStream_t s);
 bool conv_direct_supports(const VdaGemmArgs& a);              // conv_direct.hip: direct 3x3 convolution, N = 32 / 64 / 128
