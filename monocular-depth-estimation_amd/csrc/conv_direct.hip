@@ -105,8 +105,9 @@ __device__ __forceinline__ u32x4 blend2<bf16>(const u32x4& a, const u32x4& b, fl
     return __builtin_bit_cast(u32x4, o);
 }
 
-template <int TN, int TPS, bool RELU_IN, bool UP, typename T>
-__global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs p, const int tiles_x, const int tiles_y, const int two_pass) {
+template <int TN, int TPS, bool RELU_IN, bool UP, int SPEC, typename T>
+__global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs pa, const int tiles_x, const int tiles_y, const int two_pass) {
+    const VdaGemmArgs p = epi_spec_args<SPEC, T>(pa);          // the epilogue's choices as constants (EPI_SPEC_*)
     typedef typename Vec<T>::v8 frag_t;
     constexpr int N = TN * 16;
     constexpr int W_ROWS = TPS * N, W_BYTES = W_ROWS * 128, W_ITERS = W_ROWS * 8 / 256;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     }
 }
 
-template <int TN, int TPS, bool RELU_IN, bool UP, typename T>
+template <int TN, int TPS, bool RELU_IN, bool UP, int SPEC, typename T>
 int launch_cfg(const VdaGemmArgs& a, hipStream_t s) {
     const int tiles_x = (a.out_w + PT_W - 1) / PT_W, tiles_y = (a.out_h + PT_H - 1) / PT_H;
     const int imgs = a.M / (a.out_h * a.out_w);
@@ -405,23 +406,37 @@ int launch_cfg(const VdaGemmArgs& a, hipStream_t s) {
     // the separable resampling needs the 34 halo columns to come from at most 32 source columns; its second rounding is
     // 2^-12 relative in fp16 but 2^-9 in bf16, where the four-tap form is kept
     const int two_pass = UP && sizeof(T) == 2 && a.ab_type == VDA_T_F16 && 10L * (a.up_w - 1) <= 9L * (a.in_w - 1);
-    auto k = conv3_direct_kernel<TN, TPS, RELU_IN, UP, T>;
+    auto k = conv3_direct_kernel<TN, TPS, RELU_IN, UP, SPEC, T>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(imgs * tiles_x * tiles_y), a.N / (TN * 16)), dim3(256), lds, s, a, tiles_x, tiles_y, two_pass);
     return hip_rc(hipGetLastError());
 }
 
-template <bool RELU_IN, bool UP, typename T>
+template <bool RELU_IN, bool UP, int SPEC, typename T>
 int launch_r(const VdaGemmArgs& a, hipStream_t s) {
-    if (a.N % 128 == 0) return launch_cfg<8, 1, RELU_IN, UP, T>(a, s);
-    if (a.N == 64) return launch_cfg<4, 3, RELU_IN, UP, T>(a, s);
-    return launch_cfg<2, 3, RELU_IN, UP, T>(a, s);
+    if (a.N % 128 == 0) return launch_cfg<8, 1, RELU_IN, UP, SPEC, T>(a, s);
+    if (a.N == 64) return launch_cfg<4, 3, RELU_IN, UP, SPEC, T>(a, s);
+    return launch_cfg<2, 3, RELU_IN, UP, SPEC, T>(a, s);
 }
 
+// the forms the DPT head uses get an epilogue of their own (EPI_SPEC_*); anything else takes the general one
 template <typename T>
 int launch_t(const VdaGemmArgs& a, hipStream_t s) {
-    if (a.up_h > 0) return a.relu_in ? launch_r<true, true, T>(a, s) : launch_r<false, true, T>(a, s);
-    return a.relu_in ? launch_r<true, false, T>(a, s) : launch_r<false, false, T>(a, s);
+    const int spec = epi_spec_of(a);
+    if (a.up_h > 0) {
+        if (a.relu_in) return launch_r<true, true, EPI_SPEC_GENERAL, T>(a, s);
+        if (spec == EPI_SPEC_OWN) return launch_r<false, true, EPI_SPEC_OWN, T>(a, s);
+        if (spec == EPI_SPEC_DOT) return launch_r<false, true, EPI_SPEC_DOT, T>(a, s);
+        return launch_r<false, true, EPI_SPEC_GENERAL, T>(a, s);
+    }
+    if (a.relu_in) {
+        if (spec == EPI_SPEC_OWN_RELU) return launch_r<true, false, EPI_SPEC_OWN_RELU, T>(a, s);
+        return launch_r<true, false, EPI_SPEC_GENERAL, T>(a, s);
+    }
+    if (spec == EPI_SPEC_OWN) return launch_r<false, false, EPI_SPEC_OWN, T>(a, s);
+    if (spec == EPI_SPEC_OWN_RES) return launch_r<false, false, EPI_SPEC_OWN_RES, T>(a, s);
+    if (spec == EPI_SPEC_OWN_RES2) return launch_r<false, false, EPI_SPEC_OWN_RES2, T>(a, s);
+    return launch_r<false, false, EPI_SPEC_GENERAL, T>(a, s);
 }
 
 }  // namespace

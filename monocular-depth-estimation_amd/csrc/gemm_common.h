@@ -291,7 +291,7 @@ enum {
     EPI_SPEC_F32 = 7,            // plain, fp32 output, bias
     EPI_SPEC_OWN_RELU = 8,       // plain, own-type output, bias, ReLU
     EPI_SPEC_OWN_RES2 = 9,       // plain, own-type output, bias + two own-type residuals
-    EPI_SPEC_COUNT = 10
+    EPI_SPEC_DOT = 10            // ReLU, dot with a vector, ReLU: fp32 output (the direct convolution's tail form)
 };
 
 // the specialisation that describes this call exactly, or EPI_SPEC_GENERAL
@@ -299,6 +299,7 @@ inline int epi_spec_of(const VdaGemmArgs& a) {
     const int own = a.ab_type == VDA_T_F16 ? VDA_T_F16 : VDA_T_BF16;
     if (a.gamma) return EPI_SPEC_GENERAL;
     if (a.epi == VDA_EPI_GEGLU) return a.out_type == own ? EPI_SPEC_GEGLU : EPI_SPEC_GENERAL;
+    if (a.epi == VDA_EPI_DOT) return EPI_SPEC_DOT;
     if (a.epi != VDA_EPI_PLAIN) return EPI_SPEC_GENERAL;
     if (a.resid2) return a.out_type == own && a.resid_type == own && a.act == VDA_ACT_NONE ? EPI_SPEC_OWN_RES2 : EPI_SPEC_GENERAL;
     if (a.out_type == own) {
@@ -314,22 +315,26 @@ inline int epi_spec_of(const VdaGemmArgs& a) {
     return EPI_SPEC_GENERAL;
 }
 
-template <int SPEC, typename T, int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue_spec(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq, char* stage) {
-    if (SPEC == EPI_SPEC_GENERAL) {
-        gemm_epilogue<TM, TN>(p, acc, mrow0, ncol0, fq, stage);
-        return;
-    }
+// the arguments with the choices of SPEC written in as constants
+template <int SPEC, typename T>
+__device__ __forceinline__ VdaGemmArgs epi_spec_args(const VdaGemmArgs& p) {
+    if (SPEC == EPI_SPEC_GENERAL) return p;
     constexpr int own = Vec<T>::is_bf16 ? VDA_T_BF16 : VDA_T_F16;
     VdaGemmArgs q = p;
     q.gamma = nullptr;
-    q.epi = SPEC == EPI_SPEC_GEGLU ? VDA_EPI_GEGLU : VDA_EPI_PLAIN;
+    q.epi = SPEC == EPI_SPEC_GEGLU ? VDA_EPI_GEGLU : SPEC == EPI_SPEC_DOT ? VDA_EPI_DOT : VDA_EPI_PLAIN;
     q.act = SPEC == EPI_SPEC_OWN_GELU ? VDA_ACT_GELU : SPEC == EPI_SPEC_OWN_RELU ? VDA_ACT_RELU : VDA_ACT_NONE;
-    q.out_type = (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_F32) ? VDA_T_F32 : own;
+    q.out_type = (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_F32 || SPEC == EPI_SPEC_DOT) ? VDA_T_F32 : own;
     q.resid_type = (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_OWN_RES32) ? VDA_T_F32
                    : (SPEC == EPI_SPEC_OWN_RES || SPEC == EPI_SPEC_OWN_RES2) ? own : VDA_T_NONE;
     if (q.resid_type == VDA_T_NONE) q.resid = nullptr;
     if (SPEC != EPI_SPEC_OWN_RES2) q.resid2 = nullptr;
+    return q;
+}
+
+template <int SPEC, typename T, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_spec(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq, char* stage) {
+    const VdaGemmArgs q = epi_spec_args<SPEC, T>(p);
     gemm_epilogue<TM, TN>(q, acc, mrow0, ncol0, fq, stage);
 }
 
