@@ -141,19 +141,25 @@ int launch_k(const VdaGemmArgs& a, hipStream_t s) {
     return hip_rc(hipGetLastError());
 }
 
+// specialised epilogues (EPI_SPEC_*) for the forms the model uses; anything else takes the general one
 template <int BM, int BN, int WM, int WN, typename T>
 int launch_t(const VdaGemmArgs& a, hipStream_t s) {
-    if (a.a_mode == VDA_A_CONV3) return launch_k<BM, BN, WM, WN, VDA_A_CONV3, EPI_SPEC_GENERAL, T>(a, s);
-    if (BM == 128 && BN == 128) {           // the tile that carries the head's and ViT-S's linears: specialised epilogues
-        switch (epi_spec_of(a)) {
-#define VDA_CASE128(SPEC) case SPEC: return launch_k<BM, BN, WM, WN, VDA_A_LINEAR, (BM == 128 && BN == 128) ? SPEC : EPI_SPEC_GENERAL, T>(a, s);
-            VDA_CASE128(EPI_SPEC_OWN) VDA_CASE128(EPI_SPEC_OWN_GELU) VDA_CASE128(EPI_SPEC_F32_RES32) VDA_CASE128(EPI_SPEC_OWN_RES)
-            VDA_CASE128(EPI_SPEC_OWN_RES32) VDA_CASE128(EPI_SPEC_GEGLU) VDA_CASE128(EPI_SPEC_F32)
-#undef VDA_CASE128
-            default: break;
+    const int spec = epi_spec_of(a);
+#define VDA_CASE(MODE, SPEC) case SPEC: return launch_k<BM, BN, WM, WN, MODE, SPEC, T>(a, s);
+    if (a.a_mode == VDA_A_CONV3) {
+        switch (spec) {
+            VDA_CASE(VDA_A_CONV3, EPI_SPEC_OWN) VDA_CASE(VDA_A_CONV3, EPI_SPEC_OWN_RES) VDA_CASE(VDA_A_CONV3, EPI_SPEC_OWN_RELU)
+            VDA_CASE(VDA_A_CONV3, EPI_SPEC_OWN_RES2)
+            default: return launch_k<BM, BN, WM, WN, VDA_A_CONV3, EPI_SPEC_GENERAL, T>(a, s);
         }
     }
-    return launch_k<BM, BN, WM, WN, VDA_A_LINEAR, EPI_SPEC_GENERAL, T>(a, s);
+    switch (spec) {
+        VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_GELU) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_F32_RES32)
+        VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_RES) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_RES32) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_GEGLU)
+        VDA_CASE(VDA_A_LINEAR, EPI_SPEC_F32)
+        default: return launch_k<BM, BN, WM, WN, VDA_A_LINEAR, EPI_SPEC_GENERAL, T>(a, s);
+    }
+#undef VDA_CASE
 }
 
 template <int BM, int BN, int WM, int WN>
