@@ -156,7 +156,7 @@ int launch_t(const VdaGemmArgs& a, hipStream_t s) {
     switch (spec) {
         VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_GELU) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_F32_RES32)
         VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_RES) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_RES32) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_GEGLU)
-        VDA_CASE(VDA_A_LINEAR, EPI_SPEC_F32)
+        VDA_CASE(VDA_A_LINEAR, EPI_SPEC_F32) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_CONVT)
         default: return launch_k<BM, BN, WM, WN, VDA_A_LINEAR, EPI_SPEC_GENERAL, T>(a, s);
     }
 #undef VDA_CASE
@@ -220,14 +220,17 @@ extern "C" int vda_gemm(const VdaGemmArgs* args, void* stream) {
     if (a.N <= 64) return launch<128, 64, 2, 2>(a, s);
     // The 256x256 pipelined kernel moves half as many bytes global -> LDS per MFMA as the 128x128 one, which is what bounds
     // the latter (about 30 B/clk/CU of copy throughput on either); but it runs one workgroup per CU, so nothing overlaps a
-    // tile's prologue and its output stores.  It wins once the K loop amortises those and the grid still fills the chip
-    // (measured at M = 43840: K = 4096 1208 vs 870 TFLOP/s, K = 1024 835-953 vs 770-821; whole model +6.7 %).
+    // tile's prologue and its output stores.  It wins once the K loop amortises those or the grid is many rounds deep
+    // (measured, 256x256 vs 128x128 tiles, M = 43808: K = 4096 286 vs 404 us, K = 1024 N = 3072 258 vs 302, N = 256
+    // (172 tiles) 29.9 vs 34.6; K = 512 N = 2048 106 vs 110; K = 256: N = 4096 129 vs 154, N = 768 35.5 vs 32.7;
+    // M = 175232, K = 256: N = 768 114 vs 137, N = 2048 287 vs 326, N = 256 (685 tiles) equal).
+    // Both kernels add the K steps in the same order, so the choice does not change results.
     const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    // (with a long K loop one partly filled round of large tiles still beats the small tile: K = 9216, 172-184 tiles)
-    // (and the column tiles must not be mostly padding: N = 384 wastes a quarter of two 256-wide tiles; 128x128 tiles then
+    // (the column tiles must not be mostly padding: N = 384 wastes a quarter of two 256-wide tiles; 128x128 tiles then
     // win, 96 vs 105 us at M = 43840, K = 1536)
-    const bool fills = (tiles256 >= 192 || (a.K >= 4096 && tiles256 >= 160)) && 5 * a.N >= 4 * 256 * ((a.N + 255) / 256);
-    const bool big = a.tile_cfg == 2 || (a.tile_cfg == 0 && a.N >= 192 && a.K >= 1024 && fills);
+    const bool wide = a.N >= 192 && 5 * a.N >= 4 * 256 * ((a.N + 255) / 256);
+    const bool fills = a.K >= 1024 ? tiles256 >= 160 : a.K >= 512 ? tiles256 >= 1024 : a.K >= 256 && tiles256 >= 1800;
+    const bool big = a.tile_cfg == 2 || (a.tile_cfg == 0 && wide && fills);
     if (big) return launch_gemm256(a, s);
     return launch<128, 128, 2, 2>(a, s);
 }

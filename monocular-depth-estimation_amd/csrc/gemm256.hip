@@ -243,7 +243,7 @@ int launch_t(const VdaGemmArgs& a, hipStream_t s) {
             VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN_GELU)
             VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_F32_RES32) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN_RES)
             VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN_RES32) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_GEGLU)
-            VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_F32)
+            VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_F32) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_CONVT)
             default: VDA_LAUNCH256(VDA_A_LINEAR, false, EPI_SPEC_GENERAL);
         }
     }

@@ -291,7 +291,8 @@ enum {
     EPI_SPEC_F32 = 7,            // plain, fp32 output, bias
     EPI_SPEC_OWN_RELU = 8,       // plain, own-type output, bias, ReLU
     EPI_SPEC_OWN_RES2 = 9,       // plain, own-type output, bias + two own-type residuals
-    EPI_SPEC_DOT = 10            // ReLU, dot with a vector, ReLU: fp32 output (the direct convolution's tail form)
+    EPI_SPEC_DOT = 10,           // ReLU, dot with a vector, ReLU: fp32 output (the direct convolution's tail form)
+    EPI_SPEC_CONVT = 11          // transposed-convolution scatter, own-type output, bias
 };
 
 // the specialisation that describes this call exactly, or EPI_SPEC_GENERAL
@@ -300,6 +301,7 @@ inline int epi_spec_of(const VdaGemmArgs& a) {
     if (a.gamma) return EPI_SPEC_GENERAL;
     if (a.epi == VDA_EPI_GEGLU) return a.out_type == own ? EPI_SPEC_GEGLU : EPI_SPEC_GENERAL;
     if (a.epi == VDA_EPI_DOT) return EPI_SPEC_DOT;
+    if (a.epi == VDA_EPI_CONVT) return a.out_type == own && a.act == VDA_ACT_NONE ? EPI_SPEC_CONVT : EPI_SPEC_GENERAL;
     if (a.epi != VDA_EPI_PLAIN) return EPI_SPEC_GENERAL;
     if (a.resid2) return a.out_type == own && a.resid_type == own && a.act == VDA_ACT_NONE ? EPI_SPEC_OWN_RES2 : EPI_SPEC_GENERAL;
     if (a.out_type == own) {
@@ -322,7 +324,7 @@ __device__ __forceinline__ VdaGemmArgs epi_spec_args(const VdaGemmArgs& p) {
     constexpr int own = Vec<T>::is_bf16 ? VDA_T_BF16 : VDA_T_F16;
     VdaGemmArgs q = p;
     q.gamma = nullptr;
-    q.epi = SPEC == EPI_SPEC_GEGLU ? VDA_EPI_GEGLU : SPEC == EPI_SPEC_DOT ? VDA_EPI_DOT : VDA_EPI_PLAIN;
+    q.epi = SPEC == EPI_SPEC_GEGLU ? VDA_EPI_GEGLU : SPEC == EPI_SPEC_DOT ? VDA_EPI_DOT : SPEC == EPI_SPEC_CONVT ? VDA_EPI_CONVT : VDA_EPI_PLAIN;
     q.act = SPEC == EPI_SPEC_OWN_GELU ? VDA_ACT_GELU : SPEC == EPI_SPEC_OWN_RELU ? VDA_ACT_RELU : VDA_ACT_NONE;
     q.out_type = (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_F32 || SPEC == EPI_SPEC_DOT) ? VDA_T_F32 : own;
     q.resid_type = (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_OWN_RES32) ? VDA_T_F32
