@@ -147,28 +147,36 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
     if convt is not None:
         g.ct_h, g.ct_w, g.ct_k, g.ct_c = convt
     t = _gemm_timing
-    if t is not None and conv is None and g.ab_type == T_BF16 and N >= 192 and K >= 1024 and epi == EPI_PLAIN:
+    if t is not None and conv is None and g.ab_type == T_BF16 and N >= 192 and K >= 1024 and epi == EPI_PLAIN and gamma is None:
+        # which instantiation of the 256x256 kernel this launch takes (its epilogue form)
+        if resid is not None and resid.dtype == torch.float32 and out.dtype == torch.float32 and act == ACT_NONE and resid2 is None:
+            form = "f32_res32"
+        elif resid is None and out.dtype == a.dtype:
+            form = "own_gelu" if act == ACT_GELU else "own" if act == ACT_NONE else "other"
+        else:
+            form = "other"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _check(lib().vda_gemm(C.byref(g), _stream()), "vda_gemm")
         e1.record()
-        t.events.append((e0, e1, 2.0 * M * N * K))
+        t.events.append((e0, e1, 2.0 * M * N * K, form))
         return
     _check(lib().vda_gemm(C.byref(g), _stream()), "vda_gemm")
 
 
 class GemmTiming:
-    """Per-launch HIP-event timing of the 256x256-tile bf16 linear GEMM (the encoder's qkv / proj / fc1 / fc2 products:
-    the kernel that dominates the forward pass; the shape test below mirrors vda_gemm's choice of that kernel).
-    The events are recorded on the stream the kernel is launched on (torch's current stream)."""
+    """Per-launch HIP-event timing of the 256x256-tile bf16 linear GEMMs (the encoder's qkv / proj / fc1 / fc2 products; the
+    shape test above mirrors vda_gemm's choice of that kernel), tagged by the epilogue form = kernel instantiation they
+    take: "f32_res32" (proj, fc2), "own_gelu" (fc1), "own" (qkv).  The events are recorded on the stream the kernel is
+    launched on (torch's current stream)."""
 
     def __init__(self):
         self.events = []
 
-    def summary(self):
-        """(launches, total algorithmic FLOP, total milliseconds); call after a device synchronize."""
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.events)
-        return len(self.events), sum(f for _, _, f in self.events), ms
+    def summary(self, form=None):
+        """(launches, total algorithmic FLOP, total milliseconds) of one form or of all; call after a device synchronize."""
+        ev = [e for e in self.events if form is None or e[3] == form]
+        return len(ev), sum(e[2] for e in ev), sum(e[0].elapsed_time(e[1]) for e in ev)
 
 
 _gemm_timing = None
