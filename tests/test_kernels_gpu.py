@@ -99,6 +99,38 @@ def test_gemm_epilogue_bias_gelu_gamma_residual(M, N, K, cfg):
     close(out, F.relu(acc) + r16.float() + r2.float(), BF_OUT, "relu + 2 residuals")
 
 
+@pytest.mark.parametrize("cfg", [1, 2])
+@pytest.mark.parametrize("dt", HALVES)
+@pytest.mark.parametrize("form", ["own", "own_relu", "own_res", "own_res32", "own_res2", "f32", "f32_res32", "f32_res16"])
+def test_gemm_every_epilogue_form(form, dt, cfg):
+    """Each epilogue form the kernels are instantiated for (and one that falls back to the general epilogue, f32_res16),
+    on both tile kernels, M and N ragged against the tiles: bias, activation, residual(s) and output type combinations."""
+    M, N, K = 333, 320, 1024
+    a, w = rnd((M, K), 1, 1.0, dt), rnd((N, K), 2, 1 / math.sqrt(K), dt)
+    bias = rnd((N,), 3, 0.1, torch.float32)
+    want = a.float() @ w.float().t() + bias
+    kw = {}
+    out_dt = torch.float32 if form.startswith("f32") else dt
+    if form == "own_relu":
+        kw["act"] = hip.ACT_RELU
+        want = F.relu(want)
+    if form in ("own_res", "own_res2", "f32_res16"):
+        r = rnd((M, N), 5, 1.0, dt)
+        kw.update(resid=r, ldr=N)
+        want = want + r.float()
+    if form in ("own_res32", "f32_res32"):
+        r = rnd((M, N), 5, 1.0, torch.float32)
+        kw.update(resid=r, ldr=N)
+        want = want + r
+    if form == "own_res2":
+        r2 = rnd((M, N), 6, 1.0, dt)
+        kw.update(resid2=r2, ldr2=N)
+        want = want + r2.float()
+    out = torch.full((M, N), float("nan"), dtype=out_dt, device=DEV)
+    hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, tile_cfg=cfg, **kw)
+    close(out, want, OUT_TOL[out_dt] if out_dt != torch.float32 else 1e-4, form)
+
+
 @pytest.mark.parametrize("cfg", TILE_CFGS)
 @pytest.mark.parametrize("dt", HALVES)
 def test_gemm_geglu(dt, cfg):
