@@ -13,9 +13,11 @@
  *
  * Two storage modes share these entry points.  The default keeps activations in 16 bits.  The fp32 mode (the
  * reference's fp32=True, video_depth.py:67,136) keeps every activation in fp32 (dtype / out_type VDA_T_F32 below) and
- * still multiplies on the bf16 matrix cores: vda_split3 turns an fp32 operand into bf16 triples [hi | lo | hi], weights
- * are packed [hi | hi | lo], and one vda_gemm pass over K' = 3K accumulates hi*hi + lo*hi + hi*lo in fp32
- * (about 2^-16 relative per product, at a third of the bf16 rate instead of the sixteenth of the fp32 matrix cores).
+ * still multiplies on the 16-bit matrix cores: vda_split3 turns an fp32 operand into 16-bit triples [hi | lo | hi], weights
+ * are packed [hi | hi | lo], and one vda_gemm pass over K' = 3K accumulates hi*hi + lo*hi + hi*lo in fp32, at a third of the
+ * 16-bit rate instead of the sixteenth of the fp32 matrix cores.  With IEEE-half pieces (11 significant bits each, operands
+ * pre-scaled by powers of two into the half range and the sums scaled back, VdaGemmArgs.acc_scale) a product is good to about
+ * 2^-21 relative; with bf16 pieces (8 bits each, no scaling needed) to about 2^-16.
  */
 #ifndef VDA_HIP_H
 #define VDA_HIP_H
@@ -91,6 +93,8 @@ typedef struct VdaGemmArgs {
                              in_h x in_w, computed while the input patches are loaded: the resampled map never exists in
                              memory (util/blocks.py:154-158 -> :160 and dpt_temporal.py:88,97-100 -> dpt.py:118-119).
                              Only where the direct 3x3 kernel applies (see tile_cfg 3), else VDA_ESHAPE              */
+    float acc_scale;      /* 0 or 1: off.  Otherwise every sum acc[m][n] is multiplied by it before the epilogue: the
+                             inverse of the powers of two that a and w were scaled by before rounding (see vda_split3) */
 } VdaGemmArgs;
 
 int vda_gemm(const VdaGemmArgs* args, void* stream);
@@ -100,7 +104,7 @@ int vda_gemm(const VdaGemmArgs* args, void* stream);
  * the CU).  qkv: [frames][n_tok][3*heads*64] laid out [q | k | v] x [head][64] as produced by the fused QKV
  * projection, q already multiplied by 64^-1/2; out: [frames][n_tok][heads*64]; both of type dtype.
  * dtype VDA_T_BF16: bf16 operands.  dtype VDA_T_F32: fp32 in and out; q, k, v and the probabilities are split into
- * bf16 hi/lo pairs on the fly and every product is the three-term hi/lo sum.
+ * IEEE-half hi/lo pairs on the fly (after scaling by powers of two) and every product is the three-term hi/lo sum.
  * Replaces attention.py:51-59 of the reference (dinov2_layers).
  * ------------------------------------------------------------------------------------------------------------- */
 int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, int dtype, void* stream);
@@ -150,9 +154,11 @@ int vda_im2col_patch14(const float* x, void* out, int frames, int H, int W, int 
 int vda_assemble_tokens(const float* tok, const float* cls, const float* pos, float* x, int frames, int hw, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * fp32 mode operand split: x fp32 [rows][ldx] -> out bf16 [rows][3*Cp], segments [hi | lo | hi] of Cp columns each
- * (Cp % 64 == 0, columns C..Cp-1 zero, C % 4 == 0), hi = bf16(v), lo = bf16(v - hi).  `act` is applied to v first, because
- * an activation cannot be applied to hi and lo separately:
+ * fp32 mode operand split: x fp32 [rows][ldx] -> out of out_type (BF16 or F16) [rows][3*Cp], segments [hi | lo | hi] of Cp
+ * columns each (Cp % 64 == 0, columns C..Cp-1 zero, C % 4 == 0), hi = round(scale * v), lo = round(scale * v - hi); `scale` > 0
+ * is a power of two chosen by the caller (1 for bf16; for IEEE halves one that keeps |scale * v| below 65504 and the values
+ * that matter above 2^-3, so that lo is a normal half; hi saturates instead of overflowing).  `act` is applied to v first,
+ * because an activation cannot be applied to hi and lo separately:
  *   VDA_SPLIT_RELU   max(v, 0): the pre-activation of util/blocks.py:78;
  *   VDA_SPLIT_GELU   exact-form GELU (mlp.py:37): in the fp32 mode fc1 stores its pre-activation and fc2's operand is
  *                    split here (vda_gemm's own GELU is accurate to 16-bit storage only);
@@ -163,7 +169,7 @@ int vda_assemble_tokens(const float* tok, const float* cls, const float* pos, fl
  * [Cout][9][hi | hi | lo].  No counterpart in the reference (its fp32 path multiplies in fp32).
  * ------------------------------------------------------------------------------------------------------------- */
 enum { VDA_SPLIT_NONE = 0, VDA_SPLIT_RELU = 1, VDA_SPLIT_GELU = 2, VDA_SPLIT_GEGLU = 3 };
-int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int act, void* stream);
+int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int act, int out_type, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Frame preprocessing: uint8 RGB frames [frames][h0][w0][3] -> fp32 [frames][3][H][W]: x/255, bicubic resize with

@@ -192,9 +192,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
     }
 }
 
-// fp32 storage mode: q, k, v and the output are fp32.  K and V tiles are split into bf16 hi/lo images while they are
+// fp32 storage mode: q, k, v and the output are fp32.  K and V tiles are split into IEEE-half hi/lo images while they are
 // staged (registers -> LDS), q and the probabilities are split in registers, and every product is the three-term sum
-// hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation.  Same structure as attn_kernel<1> otherwise.
+// hi*hi + hi*lo + lo*hi on the fp16 matrix cores with fp32 accumulation.  Values are multiplied by powers of two before
+// the split (q, k, v by QKV_SCALE, probabilities, which reach e^DEFER = 55, by P_SCALE) so that the low halves are normal
+// numbers, and the sums are scaled back.  Same structure as attn_kernel<1> otherwise.
+constexpr float QKV_SCALE = 16.f, P_SCALE = 256.f;
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x4 read_tr_f16(const char* p) {     // transposed 4 x 16 block read of 16-bit patterns
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(p)));
+}
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n_tok,
                                                             int heads, int q_blocks) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 32768];      // per buffer: K hi, K lo, V hi, V lo (8 KiB each)
@@ -209,16 +216,16 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restr
     const float* base = qkv + (size_t)frame * n_tok * ld + head * 64;
     const int q0 = qb * 128 + wave * 32;
 
-    auto split8 = [](const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
+    auto split8 = [](const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            bf16 x, y;
-            split_bf16(a[k], x, y); hi[k] = x; lo[k] = y;
-            split_bf16(b[k], x, y); hi[4 + k] = x; lo[4 + k] = y;
+            f16 x, y;
+            split_f16(a[k] * QKV_SCALE, x, y); hi[k] = x; lo[k] = y;
+            split_f16(b[k] * QKV_SCALE, x, y); hi[4 + k] = x; lo[4 + k] = y;
         }
     };
 
-    bf16x8 qhi[4], qlo[4];
+    f16x8 qhi[4], qlo[4];
     {
         const float* qrow = base + (size_t)min(q0 + r, n_tok - 1) * ld + 8 * h;
 #pragma unroll
@@ -245,13 +252,13 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = i * 32 + srow;
-            bf16x8 hi, lo;
+            f16x8 hi, lo;
             split8(kreg[i][0], kreg[i][1], hi, lo);
-            *reinterpret_cast<bf16x8*>(b0 + tile_off(row, sc)) = hi;
-            *reinterpret_cast<bf16x8*>(b0 + 8192 + tile_off(row, sc)) = lo;
+            *reinterpret_cast<f16x8*>(b0 + tile_off(row, sc)) = hi;
+            *reinterpret_cast<f16x8*>(b0 + 8192 + tile_off(row, sc)) = lo;
             split8(vreg[i][0], vreg[i][1], hi, lo);
-            *reinterpret_cast<bf16x8*>(b0 + 16384 + v_off(row, sc * 8)) = hi;
-            *reinterpret_cast<bf16x8*>(b0 + 24576 + v_off(row, sc * 8)) = lo;
+            *reinterpret_cast<f16x8*>(b0 + 16384 + v_off(row, sc * 8)) = hi;
+            *reinterpret_cast<f16x8*>(b0 + 24576 + v_off(row, sc * 8)) = lo;
         }
     };
 
@@ -283,13 +290,15 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restr
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int off = tile_off(32 * kbk + r, 2 * ks + h);
-                const bf16x8 khi = *reinterpret_cast<const bf16x8*>(kh + off);
-                const bf16x8 klo = *reinterpret_cast<const bf16x8*>(kl + off);
-                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qhi[ks], s[kbk], 0, 0, 0);
-                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qlo[ks], s[kbk], 0, 0, 0);
-                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qhi[ks], s[kbk], 0, 0, 0);
+                const f16x8 khi = *reinterpret_cast<const f16x8*>(kh + off);
+                const f16x8 klo = *reinterpret_cast<const f16x8*>(kl + off);
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qhi[ks], s[kbk], 0, 0, 0);
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qlo[ks], s[kbk], 0, 0, 0);
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qhi[ks], s[kbk], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) s[kbk] *= 1.0f / (QKV_SCALE * QKV_SCALE);
         if (kt == nkt - 1) {
 #pragma unroll
             for (int kbk = 0; kbk < 2; ++kbk)
@@ -315,15 +324,15 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restr
         }
         const float mneg = -m_run * LOG2E;
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
-        bf16x8 ph[2][2], pl[2][2];
+        f16x8 ph[2][2], pl[2][2];
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float pv = exp2f(fmaf(s[kbk][i], LOG2E, mneg));       // full-precision exp2 in this mode
                 ps[i & 3] += pv;
-                bf16 x, y;
-                split_bf16(pv, x, y);
+                f16 x, y;
+                split_f16(pv * P_SCALE, x, y);
                 ph[kbk][i >> 3][i & 7] = x;
                 pl[kbk][i >> 3][i & 7] = y;
             }
@@ -337,15 +346,15 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restr
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int k0 = 32 * kbk + 16 * s2 + 4 * h + tq;
                     const int o0 = v_off(k0, 32 * db + tcol), o1 = v_off(k0 + 8, 32 * db + tcol);
-                    const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vh + o0));
-                    const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vh + o1));
-                    const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vl + o0));
-                    const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vl + o1));
-                    const bf16x8 vhi = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                    const bf16x8 vlo = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlo, ph[kbk][s2], o[db], 0, 0, 0);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vhi, pl[kbk][s2], o[db], 0, 0, 0);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vhi, ph[kbk][s2], o[db], 0, 0, 0);
+                    const f16x4 a0 = read_tr_f16(vh + o0);
+                    const f16x4 a1 = read_tr_f16(vh + o1);
+                    const f16x4 b0 = read_tr_f16(vl + o0);
+                    const f16x4 b1 = read_tr_f16(vl + o1);
+                    const f16x8 vhi = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    const f16x8 vlo = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, ph[kbk][s2], o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, pl[kbk][s2], o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, ph[kbk][s2], o[db], 0, 0, 0);
                 }
 
         if (kt + 1 < nkt) write_tile(cur ^ 1);
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restr
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
+    const float inv = 1.0f / (l_tot * (P_SCALE * QKV_SCALE));
     const int q = q0 + r;
     if (q < n_tok) {
         float* orow = out + ((size_t)frame * n_tok + q) * D + head * 64 + 4 * h;

@@ -80,4 +80,16 @@ __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
     lo = (bf16)(v - (float)hi);
 }
 
+// The same with two IEEE halves (11 significant bits each): v * scale = hi + lo up to 2^-22 |v * scale| while lo stays a
+// normal half, i.e. |v * scale| >= 2^-3; below that the error is at most 2^-25 absolute (half the subnormal step).  The
+// power-of-two `scale` moves the values of interest into that range; hi saturates at the largest finite half, so an
+// out-of-range value degrades (lo takes up the excess) instead of becoming infinite.  hi*hi + lo*hi + hi*lo then
+// reproduces an fp32 product to about 2^-21 relative.
+__device__ __forceinline__ void split_f16(float v, f16& hi, f16& lo) {
+    hi = (f16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    lo = (f16)__builtin_amdgcn_fmed3f(v - (float)hi, -65504.f, 65504.f);
+}
+__device__ __forceinline__ void split_any(float v, bf16& hi, bf16& lo) { split_bf16(v, hi, lo); }
+__device__ __forceinline__ void split_any(float v, f16& hi, f16& lo) { split_f16(v, hi, lo); }
+
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }

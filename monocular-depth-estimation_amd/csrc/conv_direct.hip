@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     }
 
     // ---- epilogue: lane (frow, fq) holds pixel frow of each m-tile and channels 16 j + 4 fq + {0..3} ----------------------------
+    scale_acc<4, TN>(p, acc);
     f32x4 bias[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)

@@ -334,8 +334,20 @@ __device__ __forceinline__ VdaGemmArgs epi_spec_args(const VdaGemmArgs& p) {
     return q;
 }
 
+// operands that were multiplied by powers of two before they were rounded (the fp32 mode's hi/lo halves): undo it on the sums
+template <int TM, int TN>
+__device__ __forceinline__ void scale_acc(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN]) {
+    if (p.acc_scale != 0.f && p.acc_scale != 1.f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] *= p.acc_scale;
+    }
+}
+
 template <int SPEC, typename T, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_spec(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq, char* stage) {
+    scale_acc<TM, TN>(p, acc);
     const VdaGemmArgs q = epi_spec_args<SPEC, T>(p);
     gemm_epilogue<TM, TN>(q, acc, mrow0, ncol0, fq, stage);
 }

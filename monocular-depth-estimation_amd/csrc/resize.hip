@@ -161,13 +161,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
     }
 }
 
-// fp32 rows -> bf16 rows of three segments [hi | lo | hi] (each Cp wide, zero beyond C): the A operand of a GEMM whose
-// weight rows are packed [hi | hi | lo], so that one bf16 MFMA pass over K' = 3 Cp accumulates hi*hi + lo*hi + hi*lo.
+// fp32 rows -> 16-bit rows of three segments [hi | lo | hi] (each Cp wide, zero beyond C) of scale * x: the A operand of a
+// GEMM whose weight rows are packed [hi | hi | lo], so that one MFMA pass over K' = 3 Cp accumulates hi*hi + lo*hi + hi*lo.
 // An activation is applied first (it cannot be applied to hi and lo separately); for VDA_SPLIT_GEGLU the input row holds
 // 2C values in blocks [16 values | 16 gates] and output column c is value * GELU(gate).
 // One workgroup per 4 rows; 32-bit index arithmetic inside a row.
-__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, bf16* __restrict__ out, long rows, int C,
-                                                     int ldx, int Cp, int act) {
+template <typename T>
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, T* __restrict__ out, long rows, int C,
+                                                     int ldx, int Cp, int act, float scale) {
     const long row0 = (long)blockIdx.x * 4;
     const int cv = Cp / 4;
     for (int i = threadIdx.x; i < 4 * cv; i += 256) {
@@ -186,21 +187,21 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
                 v = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
             }
         }
-        bf16x4 hi, lo;
+        typename Vec<T>::v4 hi, lo;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float f = v[k];
             if (act == VDA_SPLIT_RELU) f = fmaxf(f, 0.f);
             if (act == VDA_SPLIT_GELU) f = gelu_erf(f);
-            bf16 h, l;
-            split_bf16(f, h, l);
+            T h, l;
+            split_any(f * scale, h, l);
             hi[k] = h;
             lo[k] = l;
         }
-        bf16* o = out + row * (3L * Cp) + c;
-        *reinterpret_cast<bf16x4*>(o) = hi;
-        *reinterpret_cast<bf16x4*>(o + Cp) = lo;
-        *reinterpret_cast<bf16x4*>(o + 2 * Cp) = hi;
+        T* o = out + row * (3L * Cp) + c;
+        *reinterpret_cast<typename Vec<T>::v4*>(o) = hi;
+        *reinterpret_cast<typename Vec<T>::v4*>(o + Cp) = lo;
+        *reinterpret_cast<typename Vec<T>::v4*>(o + 2 * Cp) = hi;
     }
 }
 
@@ -257,14 +258,21 @@ extern "C" int vda_im2col_patch14(const float* x, void* out, int frames, int H, 
     return hip_rc(hipGetLastError());
 }
 
-extern "C" int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int act, void* stream) {
+extern "C" int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int act, int out_type, float scale,
+                          void* stream) {
     if (!x || !out || rows <= 0 || C <= 0) return VDA_EINVAL;
     if (act < VDA_SPLIT_NONE || act > VDA_SPLIT_GEGLU) return VDA_EINVAL;
+    if ((out_type != VDA_T_BF16 && out_type != VDA_T_F16) || !(scale > 0.f)) return VDA_EINVAL;
     const int in_cols = act == VDA_SPLIT_GEGLU ? 2 * C : C;
     if (C % 4 != 0 || Cp % 64 != 0 || Cp < C || ldx < in_cols || ldx % 4 != 0 || (rows + 3) / 4 > 0x7fffffffL) return VDA_ESHAPE;
     if (act == VDA_SPLIT_GEGLU && C % 16 != 0) return VDA_ESHAPE;
-    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                       reinterpret_cast<bf16*>(out), rows, C, ldx, Cp, act);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (out_type == VDA_T_F16)
+        hipLaunchKernelGGL(split3_kernel<f16>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                           reinterpret_cast<f16*>(out), rows, C, ldx, Cp, act, scale);
+    else
+        hipLaunchKernelGGL(split3_kernel<bf16>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                           reinterpret_cast<bf16*>(out), rows, C, ldx, Cp, act, scale);
     return hip_rc(hipGetLastError());
 }
 

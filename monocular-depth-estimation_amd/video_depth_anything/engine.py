@@ -14,6 +14,7 @@ torch is used for allocation (caching allocator = workspace reuse) and the strea
 import torch
 
 from . import hip
+from .packing import ACT_SPLIT_SCALE, SPLIT_DTYPE, SplitWeight
 from .spec import TEMPORAL_HEADS
 
 BF16 = torch.bfloat16
@@ -30,6 +31,7 @@ class Engine:
         self.split = packed.precision == "fp32"
         self.hdt = packed.head_dtype         # storage/operand type of the DPT head and the temporal modules
         self.edt = torch.float32 if self.split else BF16      # storage type of the encoder's GEMM operands
+        self.act_scale = ACT_SPLIT_SCALE if SPLIT_DTYPE == torch.float16 else 1.0
 
     # ---- small wrappers -------------------------------------------------------------------------------------------
     def operand(self, a, relu=False, act=None):
@@ -41,14 +43,22 @@ class Engine:
         rows, K = a.shape
         if act == hip.SPLIT_GEGLU:
             K //= 2
-        a3 = _empty((rows, 3 * K), BF16, self.dev)
-        hip.split3(a, a3, rows, K, a.stride(0), K, relu=relu, act=act)
+        a3 = _empty((rows, 3 * K), SPLIT_DTYPE, self.dev)
+        hip.split3(a, a3, rows, K, a.stride(0), K, relu=relu, act=act, scale=self.act_scale)
         return a3, False
+
+    def weight(self, w, kw):
+        """The device tensor of a packed weight; for the fp32 mode's scaled hi/lo pieces also sets the GEMM's ``acc_scale``."""
+        if isinstance(w, SplitWeight):
+            kw["acc_scale"] = 1.0 / (w.scale * self.act_scale)
+            return w.t
+        return w
 
     def linear(self, a, w, out, bias=None, a_act=None, **kw):
         a, _ = self.operand(a, act=a_act)
         M, K = a.shape[0], a.shape[-1]
         N = kw.pop("N", w.shape[0])
+        w = self.weight(w, kw)
         hip.gemm(a, w, out, M=M, N=N, K=K, lda=a.stride(0), ldc=kw.pop("ldc", out.stride(0)), bias=bias, **kw)
         return out
 
@@ -64,7 +74,7 @@ class Engine:
                 h, wd = resized
                 if out is None:
                     out = _empty((f, h, wd, cout), self.hdt, self.dev)
-                hip.gemm(x.reshape(f * sh * sw, cin), w, out, M=f * h * wd, N=cout, K=9 * cin, lda=0,
+                hip.gemm(x.reshape(f * sh * sw, cin), self.weight(w, kw), out, M=f * h * wd, N=cout, K=9 * cin, lda=0,
                          ldc=cout if ldc is None else ldc, bias=bias, relu_in=relu_in, conv=(h, wd, cin, h, wd, 1),
                          upsample_from=(sh, sw), **kw)
                 return out
@@ -74,7 +84,7 @@ class Engine:
             out = _empty((f, oh, ow, cout), self.hdt, self.dev)
         a, relu_in = self.operand(x.reshape(f * h * wd, cin), relu_in)
         cin = a.shape[1]
-        hip.gemm(a, w, out, M=f * oh * ow, N=cout, K=9 * cin, lda=0, ldc=cout if ldc is None else ldc, bias=bias,
+        hip.gemm(a, self.weight(w, kw), out, M=f * oh * ow, N=cout, K=9 * cin, lda=0, ldc=cout if ldc is None else ldc, bias=bias,
                  relu_in=relu_in, conv=(h, wd, cin, oh, ow, stride), **kw)
         return out
 

@@ -36,7 +36,7 @@ class GemmArgs(C.Structure):
         ("ab_type", C.c_int), ("relu_in", C.c_int),
         ("in_h", C.c_int), ("in_w", C.c_int), ("cin", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int), ("stride", C.c_int),
         ("ct_h", C.c_int), ("ct_w", C.c_int), ("ct_k", C.c_int), ("ct_c", C.c_int), ("tile_cfg", C.c_int),
-        ("up_h", C.c_int), ("up_w", C.c_int),
+        ("up_h", C.c_int), ("up_w", C.c_int), ("acc_scale", C.c_float),
     ]
 
 
@@ -61,7 +61,8 @@ def lib():
         l.vda_bilinear_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
         l.vda_bilinear_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         l.vda_im2col_patch14.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        l.vda_split3.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.vda_split3.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                 C.c_void_p]
         l.vda_assemble_tokens.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]
         l.vda_temporal_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                              C.c_int, C.c_void_p]
@@ -114,9 +115,11 @@ def zero_page(device):
 
 
 def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr=0, resid2=None, ldr2=0, act=ACT_NONE,
-         epi=EPI_PLAIN, relu_in=False, conv=None, convt=None, dot_w=None, dot_b=0.0, tile_cfg=None, upsample_from=None):
+         epi=EPI_PLAIN, relu_in=False, conv=None, convt=None, dot_w=None, dot_b=0.0, tile_cfg=None, upsample_from=None,
+         acc_scale=1.0):
     """Enqueue one vda_gemm.  ``conv`` = (in_h, in_w, cin, out_h, out_w, stride); ``convt`` = (h, w, k, c);
-    ``upsample_from`` = (h, w) of the map ``a`` that is bilinearly resampled to in_h x in_w on the fly."""
+    ``upsample_from`` = (h, w) of the map ``a`` that is bilinearly resampled to in_h x in_w on the fly;
+    ``acc_scale`` multiplies every sum before the epilogue (operands pre-scaled by powers of two)."""
     _dev(a, w, out, bias, gamma, resid, resid2, dot_w)
     g = GemmArgs()
     g.a, g.w, g.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -128,6 +131,7 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
     g.dot_b = float(dot_b)
     g.M, g.N, g.K, g.lda, g.ldc, g.ldr, g.ldr2 = M, N, K, lda, ldc, ldr, ldr2
     g.act, g.epi, g.relu_in = act, epi, int(bool(relu_in))
+    g.acc_scale = float(acc_scale)
     g.tile_cfg = TILE_CFG if tile_cfg is None else tile_cfg
     if a.dtype != w.dtype:
         raise TypeError("vda_gemm: a and w must share one 16-bit type")
@@ -203,13 +207,13 @@ def attention(qkv, out, frames, n_tok, heads):
 SPLIT_NONE, SPLIT_RELU, SPLIT_GELU, SPLIT_GEGLU = 0, 1, 2, 3
 
 
-def split3(x, out, rows, Cdim, ldx, Cp, relu=False, act=None):
-    """fp32 [rows][ldx] -> bf16 [rows][3*Cp] segments [hi | lo | hi] (the A operand of the fp32 mode's GEMMs), after the
-    activation ``act`` (SPLIT_*; ``relu=True`` is SPLIT_RELU)."""
+def split3(x, out, rows, Cdim, ldx, Cp, relu=False, act=None, scale=1.0):
+    """fp32 [rows][ldx] -> 16-bit [rows][3*Cp] segments [hi | lo | hi] of ``scale * x`` in ``out``'s type (bf16 or fp16): the
+    A operand of the fp32 mode's GEMMs, after the activation ``act`` (SPLIT_*; ``relu=True`` is SPLIT_RELU)."""
     _dev(x, out)
     if act is None:
         act = SPLIT_RELU if relu else SPLIT_NONE
-    _check(lib().vda_split3(_ptr(x), _ptr(out), rows, Cdim, ldx, Cp, int(act), _stream()), "vda_split3")
+    _check(lib().vda_split3(_ptr(x), _ptr(out), rows, Cdim, ldx, Cp, int(act), _type(out), float(scale), _stream()), "vda_split3")
 
 
 def layernorm(x, out, weight, bias, rows, Cdim, eps, rows_per_group=None, in_group=None, in_skip=0, pe=None, pe_hw=1, pe_T=1):

@@ -64,17 +64,43 @@ def resample_pos_embed(pos_embed, hp, wp):
     return np.concatenate([pe[:1], out.reshape(hp * wp, -1).astype(np.float32)], axis=0)
 
 
+SPLIT_DTYPE = torch.float16      # piece type of the fp32 mode's hi/lo operands (torch.bfloat16: 8-bit pieces, no scaling)
+ACT_SPLIT_SCALE = 16.0           # power of two every fp32 activation is multiplied by before it is split into halves:
+#                                  values down to 2^-7 keep a normal low half, values up to 4094 fit the high half
+
+
+class SplitWeight:
+    """A weight matrix packed for the fp32 mode: ``t`` = 16-bit [..., 3K] laid out [hi | hi | lo] along the last axis (the
+    activation side is [hi | lo | hi], see vda_split3), pieces of ``scale * w``; ``scale`` is the power of two that puts
+    the largest |w| just below 2048, so that the low halves are normal IEEE halves."""
+
+    def __init__(self, w, dtype=None):
+        dtype = dtype or SPLIT_DTYPE
+        self.scale = 1.0
+        if dtype == torch.float16:
+            top = float(w.abs().max())
+            self.scale = 2.0 ** (10 - math.floor(math.log2(top))) if top > 0 else 1.0
+        ws = w * self.scale
+        hi = ws.to(dtype)
+        lo = (ws - hi.float()).to(dtype)
+        self.t = torch.cat([hi, hi, lo], dim=-1).contiguous()
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    def reshape(self, *shape):
+        self.t = self.t.reshape(*shape)
+        return self
+
+
 def split_weight(w):
-    """fp32 [..., K] -> bf16 [..., 3K] laid out [hi | hi | lo] along the last axis: the weight side of the fp32 mode's
-    three-term product (the activation side is [hi | lo | hi], see vda_split3)."""
-    hi = w.to(BF16)
-    lo = (w - hi.float()).to(BF16)
-    return torch.cat([hi, hi, lo], dim=-1).contiguous()
+    return SplitWeight(w)
 
 
 class PackedWeights:
-    """Device-resident kernel-layout weights of one model.  ``precision`` "fp32" packs every matrix as bf16 hi/lo triples
-    for the fp32 storage mode (``head_dtype`` is then ignored)."""
+    """Device-resident kernel-layout weights of one model.  ``precision`` "fp32" packs every matrix as 16-bit hi/lo triples
+    (``SplitWeight``) for the fp32 storage mode (``head_dtype`` is then ignored)."""
 
     def __init__(self, sd, encoder, features, out_channels, device, head_dtype=torch.float16, precision="half"):
         self.device = device

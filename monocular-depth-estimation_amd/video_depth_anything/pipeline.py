@@ -1,22 +1,30 @@
 """Whole-video inference around ``VideoDepthAnything.forward`` (reference: video_depth.py:67-209).
 
 Differences from the reference's data flow (results are the same function of the frames):
-  * frames are uploaded once as uint8 and preprocessed on the device; a frame that appears in two windows is
+  * frames are uploaded once as uint8 and preprocessed on the device; a frame that appears in several windows is
     preprocessed once and cached, instead of a 103 MB fp32 host->device copy per window;
   * the full-resolution upsample, the least-squares alignment and the cross-fade run on the device; only final maps are
-    copied back;
-  * with ``torch.distributed`` initialised (one process per GPU, backend "nccl" = RCCL) the windows are split into
-    contiguous blocks per rank.  A window depends only on INPUT frames, so ranks compute independently; afterwards the
-    ranks all-gather, per window, the three maps the alignment chain needs (slots 0, 1, 12) plus each rank's last eight
-    raw maps for the cross-fade at rank boundaries, replay the (cheap) sequential fit, align their own frames and gather
-    the result.
+    copied back, from a side stream, into a small ring of pinned buffers, while the next window is computed;
+  * with ``torch.distributed`` initialised (one process per GPU, backend "nccl" = RCCL) the windows are dealt round-robin:
+    window w runs on rank w % world.  A window depends only on INPUT frames, so the ranks compute a round of ``world``
+    windows independently.  Per round each rank then contributes the eleven raw maps of its window that other ranks need
+    -- slots 0, 1, 12 (the alignment chain, video_depth.py:180-201) and slots 24..31 (the cross-fade partner of the next
+    window, :189) -- to ONE all-gather, issued asynchronously so that it travels while the next round is computed.
+    Every rank replays the round's cheap sequential fits, aligns the frames of its own window and streams them to its
+    host.  No final frame crosses the links unless the caller wants every rank to return the whole video
+    (``shard_output="replicate"``, the default, for drop-in callers; "local" keeps a rank's frames on that rank).
 """
+from collections import OrderedDict
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import hip
-from .windows import INFER_LEN, INTERP_LEN, OVERLAP, Stitcher, network_size, partition, resolve_plan, window_plan
+from .windows import INFER_LEN, INTERP_LEN, OVERLAP, Aligner, network_size, partition, resolve_plan, window_plan
+
+KEY_SLOTS = (0, 1, 12)                      # raw maps of a window that the alignment chain reads
+PACK = len(KEY_SLOTS) + INTERP_LEN          # maps a rank contributes per round: the key maps and the 8-map tail
 
 
 def _dist_state():
@@ -26,92 +34,152 @@ def _dist_state():
 
 
 class FrameSource:
-    """Preprocessed network-size frames on the device, computed on demand from the uint8 video and cached.  The frames a
-    window is missing are staged through one pinned host buffer, uploaded with one asynchronous copy and preprocessed by
-    one kernel launch."""
+    """Preprocessed network-size frames on the device, computed on demand from the uint8 video and cached (least recently
+    used frames are dropped first, so the key frames every window re-reads stay resident).  The frames a window is missing
+    are staged through one pinned host buffer, uploaded with one asynchronous copy and preprocessed by one kernel launch."""
 
-    def __init__(self, frames, H, W, device, keep=64):
+    def __init__(self, frames, H, W, device, keep=96):
         self.frames, self.H, self.W, self.dev, self.keep = frames, H, W, device, keep
-        self.cache = {}
+        self.cache = OrderedDict()
+        self.stage = None
+        self.uploaded = None         # event: the last upload from `stage` has been read
 
     def window(self, ids):
         """fp32 [len(ids), 3, H, W] for the given video frame indices (repeats allowed)."""
         missing = sorted({i for i in ids if i not in self.cache})
         if missing:
             h0, w0 = self.frames[missing[0]].shape[:2]
-            stage = torch.empty((len(missing), h0, w0, 3), dtype=torch.uint8)
-            if self.dev.type == "cuda":
-                stage = stage.pin_memory()
-            host = stage.numpy()
+            if self.stage is None or self.stage.shape[0] < len(missing):
+                self.stage = torch.empty((max(len(missing), INFER_LEN), h0, w0, 3), dtype=torch.uint8)
+                if self.dev.type == "cuda":
+                    self.stage = self.stage.pin_memory()
+            elif self.uploaded is not None:
+                self.uploaded.synchronize()                     # the previous upload from this buffer has been read
+            host = self.stage.numpy()
             for j, i in enumerate(missing):
                 f = self.frames[i]
                 host[j] = f if f.dtype == np.uint8 else np.clip(f, 0, 255).astype(np.uint8)
-            u8 = stage.to(self.dev, non_blocking=True)
+            u8 = self.stage[: len(missing)].to(self.dev, non_blocking=True)
+            if self.dev.type == "cuda":
+                self.uploaded = torch.cuda.Event()
+                self.uploaded.record()
             t = torch.empty((len(missing), 3, self.H, self.W), dtype=torch.float32, device=self.dev)
             hip.preprocess_u8(u8, t, len(missing), h0, w0, self.H, self.W)
             for j, i in enumerate(missing):
                 self.cache[i] = t[j]
+        for i in ids:
+            self.cache.move_to_end(i)
         out = torch.stack([self.cache[i] for i in ids], 0)
-        if len(self.cache) > self.keep:
-            for k in sorted(self.cache)[: len(self.cache) - self.keep]:
-                del self.cache[k]
+        while len(self.cache) > self.keep:
+            self.cache.popitem(last=False)
         return out
 
 
 class HostSink:
-    """Final depth maps device -> host: each batch is copied into pinned memory on a side stream while the next window is
-    computed; ``result()`` waits for the copies and assembles the [n, h0, w0] array."""
+    """Final depth maps device -> host.  ``push(start, maps)`` copies a run of consecutive video frames into one of a few
+    pinned staging buffers on a side stream while the next window is computed; completed copies are drained into the
+    [n, h0, w0] result on later pushes, so pinned memory stays at ``ring`` windows whatever the video length."""
 
-    def __init__(self, n, h0, w0, device):
-        self.out = np.empty((n, h0, w0), dtype=np.float32)
-        self.n, self.done, self.pending = n, 0, []
+    def __init__(self, n, h0, w0, device, ring=3):
+        self.out = np.zeros((n, h0, w0), dtype=np.float32)      # untouched pages cost nothing (frames of other ranks)
+        self.have = np.zeros(n, dtype=bool)
+        self.n, self.pending, self.free, self.ring, self.made = n, [], [], ring, 0
         # host tensors (the CPU doubles the host-logic tests run this module with) are copied synchronously
         self.stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
 
-    def push(self, maps):
-        k = min(len(maps), self.n - self.done)
+    def _drain(self, block_all):
+        while self.pending and (block_all or self.pending[0][0].query()):
+            copied, host, start, k = self.pending.pop(0)
+            copied.synchronize()
+            self.out[start:start + k] = host[:k].numpy()
+            self.free.append(host)
+
+    def push(self, start, maps):
+        k = min(len(maps), self.n - start)
         if k <= 0:
             return
         block = torch.stack(list(maps[:k]), 0)
+        self.have[start:start + k] = True
         if self.stream is None:
-            self.out[self.done:self.done + k] = block.numpy()
-            self.done += k
+            self.out[start:start + k] = block.numpy()
             return
+        self._drain(False)
+        if not self.free and self.made >= self.ring:
+            copied, host, s0, k0 = self.pending.pop(0)            # oldest copy: wait for it and reuse its buffer
+            copied.synchronize()
+            self.out[s0:s0 + k0] = host[:k0].numpy()
+            self.free.append(host)
+        if self.free:
+            host = self.free.pop()
+        else:
+            host = torch.empty((INFER_LEN,) + tuple(block.shape[1:]), dtype=torch.float32).pin_memory()
+            self.made += 1
         ready = torch.cuda.Event()
         ready.record()
-        host = torch.empty(block.shape, dtype=torch.float32).pin_memory()
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
-            host.copy_(block, non_blocking=True)
+            host[:k].copy_(block, non_blocking=True)
             copied = torch.cuda.Event()
             copied.record(self.stream)
         block.record_stream(self.stream)
-        self.pending.append((copied, host, self.done, k))
-        self.done += k
+        self.pending.append((copied, host, start, k))
 
     def result(self):
-        for copied, host, start, k in self.pending:
-            copied.synchronize()
-            self.out[start:start + k] = host.numpy()
-        self.pending = []
+        self._drain(True)
         return self.out
 
 
-def run_video(model, frames, target_fps, input_size=518, device="cuda", batch_size=16, forward_fn=None):
+def owned_runs(n_frames, n_win, stitched, L):
+    """Per window, the (first video frame, first slot, count) of the output frames it finalises.  Stitched: window 0 gives
+    frames 0..23, window w slots 2..23 -> frames 22w+2.., the last window also its slots 24..31 (video_depth.py:176-205);
+    unstitched: window w's L slots land at output positions w*L.. (the reference concatenates, :166-168, 209)."""
+    runs = []
+    for w in range(n_win):
+        if not stitched:
+            start, slot, cnt = w * L, 0, L
+        else:
+            step = INFER_LEN - OVERLAP
+            slot = 0 if w == 0 else OVERLAP - INTERP_LEN
+            start = w * step + slot
+            cnt = (INFER_LEN if w == n_win - 1 else INFER_LEN - INTERP_LEN) - slot
+        cnt = max(0, min(cnt, n_frames - start))
+        runs.append((start, slot, cnt))
+    return runs
+
+
+def run_video(model, frames, target_fps, input_size=518, device="cuda", batch_size=16, forward_fn=None, shard_output=None):
     n = len(frames)
     if n == 0:
         raise ValueError("no frames")
     h0, w0 = frames[0].shape[:2]
-    dev = torch.device(device if device != "cuda" else f"cuda:{torch.cuda.current_device()}") if isinstance(device, str) else device
-    clamp = bool(getattr(model, "clamp_input_size_on_gpu", False)) and str(device).startswith("cuda")
+    if isinstance(device, str):
+        if device == "cuda":
+            p = next(model.parameters(), None) if model is not None else None
+            device = p.device if p is not None and p.is_cuda else f"cuda:{torch.cuda.current_device()}"
+        device = torch.device(device)
+    dev = device
+    if dev.type == "cuda":          # every launch below takes the current stream of the CURRENT device: make it `dev`
+        with torch.cuda.device(dev):
+            return _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_fn, shard_output, n, h0, w0)
+    return _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_fn, shard_output, n, h0, w0)
+
+
+def _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_fn, shard_output, n, h0, w0):
+    clamp = bool(getattr(model, "clamp_input_size_on_gpu", False)) and dev.type == "cuda"
     H, W = network_size(h0, w0, input_size, clamp_420=clamp)
     fwd = forward_fn or model.forward
+    shard_output = shard_output or getattr(model, "shard_output", "replicate")
+    if shard_output not in ("replicate", "local"):
+        raise ValueError(f"shard_output {shard_output!r}: expected 'replicate' or 'local'")
     plan, L, O = window_plan(n, batch_size)
     frame_ids = resolve_plan(plan)
     n_win = len(plan)
     world, rank = _dist_state()
-    lo, hi = partition(n_win, world, rank)
     src = FrameSource(frames, H, W, dev)
+    stitched = L == INFER_LEN and batch_size >= INFER_LEN
+    runs = owned_runs(n, n_win, stitched, L)
+    sink = HostSink(n, h0, w0, dev)
+    stats = dict(world=world, windows=n_win, rounds=-(-n_win // world), gathered_bytes_per_round=0)
 
     def raw_window(w):
         """Raw full-resolution depth [L, h0, w0] of window w."""
@@ -123,90 +191,93 @@ def run_video(model, frames, target_fps, input_size=518, device="cuda", batch_si
         hip.bilinear_f32(d, out, L, H, W, h0, w0, relu=False)
         return out
 
-    stitched = L == INFER_LEN and batch_size >= INFER_LEN
+    if not stitched:        # reference quirk: overlapping windows concatenated unaligned; nothing to exchange
+        for w in partition(n_win, world, rank):
+            d = raw_window(w)
+            start, slot, cnt = runs[w]
+            sink.push(start, [d[slot + i] for i in range(cnt)])
+    else:
+        al = Aligner(dev)
+        prev_tail = None                  # aligned slots 24..31 of the window before the next one to be finished
+        pending = None
+        rounds = stats["rounds"]
+        if world > 1:
+            stats["gathered_bytes_per_round"] = world * PACK * h0 * w0 * 4
+        for rd in range(rounds + 1):
+            cur = None
+            if rd < rounds:
+                w = rd * world + rank
+                d = raw_window(w) if w < n_win else None
+                if world > 1:
+                    pack = torch.zeros((PACK, h0, w0), dtype=torch.float32, device=dev)
+                    if d is not None:
+                        for j, s in enumerate(KEY_SLOTS):
+                            pack[j] = d[s]
+                        pack[len(KEY_SLOTS):] = d[INFER_LEN - INTERP_LEN:]
+                    # the overlap maps only; asynchronous: it travels while the next round's windows are computed
+                    packs = torch.empty((world, PACK, h0, w0), dtype=torch.float32, device=dev)
+                    if dist.get_backend() == "nccl":
+                        work = dist.all_gather_into_tensor(packs, pack, async_op=True)
+                    else:       # other backends (gloo in tests and single-GPU rehearsals): blocking, through host memory
+                        work = None
+                        parts = [torch.empty((PACK, h0, w0), dtype=torch.float32) for _ in range(world)]
+                        dist.all_gather(parts, pack.cpu())
+                        packs.copy_(torch.stack(parts, 0))
+                else:
+                    packs, work = None, None
+                cur = (rd, d, packs, work)
+            if pending is not None:
+                prd, pd, ppacks, pwork = pending
+                if pwork is not None:
+                    pwork.wait()
+                for j in range(world):
+                    w = prd * world + j
+                    if w >= n_win:
+                        break
+                    mine = j == rank
+                    if world > 1:
+                        keys, tail = ppacks[j, :len(KEY_SLOTS)], ppacks[j, len(KEY_SLOTS):]
+                    else:
+                        keys, tail = [pd[s] for s in KEY_SLOTS], pd[INFER_LEN - INTERP_LEN:]
+                    al.advance(w, keys[0], keys[1], keys[2])
+                    if mine:
+                        start, slot, cnt = runs[w]
+                        final = []
+                        for i in range(cnt):
+                            s = slot + i
+                            if w > 0 and s < OVERLAP:          # slots 2..9: cross-fade onto the previous window's tail
+                                final.append(al.blend(pd[s], prev_tail[s - (OVERLAP - INTERP_LEN)], s - (OVERLAP - INTERP_LEN)))
+                            else:
+                                final.append(al.apply(pd[s], w))
+                        sink.push(start, final)
+                    # the aligned tail of window w is read by the owner of window w + 1
+                    if w + 1 < n_win and (j + 1) % world == rank:
+                        prev_tail = [al.apply(tail[i], w) for i in range(INTERP_LEN)]
+            pending = cur
 
-    # ---- single process -------------------------------------------------------------------------------------------------
-    if world == 1:
-        sink = HostSink(n, h0, w0, dev)
-        if stitched:
-            st = Stitcher(dev)
-            for w in range(n_win):
-                sink.push(st.push(raw_window(w)))
-            sink.push(st.flush())
-        else:
-            for w in range(n_win):      # reference quirk: overlapping windows concatenated unaligned (video_depth.py:166-168)
-                d = raw_window(w)
-                sink.push([d[i] for i in range(L)])
-        return sink.result(), target_fps
+    out = sink.result()
+    owner = np.full(n, -1, dtype=np.int64)
+    for w, (start, slot, cnt) in enumerate(runs):
+        owner[start:start + cnt] = w % world
+    if model is not None:
+        model.last_owned_frames = owner == rank
+        model.last_shard_stats = stats
+    if world > 1 and shard_output == "replicate":
+        _replicate(out, owner, world, rank, dev)
+    return out, target_fps
 
-    # ---- one process per GPU ------------------------------------------------------------------------------------------------
-    mine = [raw_window(w) for w in range(lo, hi)]
-    per = -(-n_win // world)
-    if not stitched:
-        local = torch.zeros((per * L, h0, w0), dtype=torch.float32, device=dev)
-        for j, d in enumerate(mine):
-            local[j * L:(j + 1) * L] = d
-        gathered = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(gathered, local)
-        full = torch.cat(gathered, 0)[: n_win * L]
-        return full[:n].cpu().numpy(), target_fps
 
-    # key maps of every window (slots 0, 1, 12) and every rank's last 8 raw maps
-    keys = torch.zeros((per, 3, h0, w0), dtype=torch.float32, device=dev)
-    for j, d in enumerate(mine):
-        keys[j, 0], keys[j, 1], keys[j, 2] = d[0], d[1], d[12]
-    tail = mine[-1][INFER_LEN - INTERP_LEN:].contiguous() if mine else torch.zeros((INTERP_LEN, h0, w0), dtype=torch.float32, device=dev)
-    all_keys = [torch.empty_like(keys) for _ in range(world)]
-    all_tail = [torch.empty_like(tail) for _ in range(world)]
-    dist.all_gather(all_keys, keys)
-    dist.all_gather(all_tail, tail)
-    all_keys = torch.cat(all_keys, 0)[:n_win]
-
-    # replay the sequential fit over all windows (every rank, redundantly: K small reductions)
-    st = Stitcher(dev)
-    st.started = True
-    st.ref0, st.ref1 = all_keys[0, 0].contiguous(), all_keys[0, 2].contiguous()
-    scales = [None] * n_win                 # device tensors [scale, shift] per window
-    for w in range(1, n_win):
-        st.fit(all_keys[w, 0].contiguous(), all_keys[w, 1].contiguous())
-        scales[w] = st.ss.clone()
-        st.ref1 = st._affine(all_keys[w, 2].contiguous())
-
-    ident = torch.tensor([1.0, 0.0], dtype=torch.float32, device=dev)
-
-    def aligned(x, w, pre=None, w_pre=0.0, w_post=1.0):
-        out = torch.empty_like(x)
-        hip.affine_blend(x.contiguous(), pre, out, scales[w] if scales[w] is not None else ident, float(w_pre), float(w_post), x.numel())
-        return out
-
-    # frames this rank owns: window w contributes video frames 22w+2 .. 22w+23 (window 0: 0 .. 23); the very last window
-    # also owns its slots 24..31
-    pieces = []
-    for j, d in enumerate(mine):
-        w = lo + j
-        if w == 0:
-            pieces += [d[i] for i in range(INFER_LEN - INTERP_LEN)]
-        else:
-            if j > 0:
-                prev_tail, pw = mine[j - 1][INFER_LEN - INTERP_LEN:], w - 1
-            else:
-                prev_tail, pw = all_tail[rank - 1], w - 1
-            for i in range(INTERP_LEN):
-                w_post = 0.0 if i == 0 else (1.0 if i == INTERP_LEN - 1 else i * (1.0 / (INTERP_LEN - 1)))
-                pre = aligned(prev_tail[i], pw) if pw > 0 else prev_tail[i].contiguous()
-                pieces.append(aligned(d[2 + i], w, pre, 1.0 - w_post, w_post))
-            pieces += [aligned(d[i], w) for i in range(OVERLAP, INFER_LEN - INTERP_LEN)]
-        if w == n_win - 1:
-            pieces += [aligned(d[i], w) if w > 0 else d[i] for i in range(INFER_LEN - INTERP_LEN, INFER_LEN)]
-    step = INFER_LEN - OVERLAP
-    cap = per * step + INFER_LEN
-    local = torch.zeros((cap, h0, w0), dtype=torch.float32, device=dev)
-    cnt = torch.tensor([len(pieces)], dtype=torch.int64, device=dev)
-    if pieces:
-        local[: len(pieces)] = torch.stack(pieces, 0)
-    gathered = [torch.empty_like(local) for _ in range(world)]
-    counts = [torch.empty_like(cnt) for _ in range(world)]
-    dist.all_gather(gathered, local)
-    dist.all_gather(counts, cnt)
-    full = torch.cat([g[: int(c.item())] for g, c in zip(gathered, counts)], 0)
-    return full[:n].cpu().numpy(), target_fps
+def _replicate(out, owner, world, rank, dev, chunk=32):
+    """Every rank receives the frames the other ranks own (drop-in callers expect the whole video from every rank): one
+    broadcast per owner and chunk of frames, staged through the device for the RCCL backend."""
+    via_device = dist.get_backend() == "nccl"
+    for root in range(world):
+        ids = np.nonzero(owner == root)[0]
+        for c0 in range(0, len(ids), chunk):
+            sel = ids[c0:c0 + chunk]
+            buf = torch.from_numpy(out[sel]) if rank == root else torch.empty((len(sel),) + out.shape[1:], dtype=torch.float32)
+            if via_device:
+                buf = buf.to(dev)
+            dist.broadcast(buf, src=root)
+            if rank != root:
+                out[sel] = buf.cpu().numpy()

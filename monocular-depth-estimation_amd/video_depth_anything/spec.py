@@ -29,6 +29,7 @@ MODEL_CONFIGS = {
 PATCH = 14
 POS_GRID = 37          # pos_embed is stored for a 518/14 = 37 x 37 grid (dinov2.py:407)
 TEMPORAL_HEADS = 8     # dpt_temporal.py:35
+CLAMPED_PROFILE_BIAS = 4.2    # output_conv2.2.bias of the "clamped" synthetic weight profile (the mixed-sign weights sum to about -3.8 on the hidden channels)
 
 
 def state_dict_spec(encoder="vitl", features=256, out_channels=(256, 512, 1024, 1024), num_frames=32):
@@ -133,13 +134,20 @@ def sinusoid_table(T, C):
 
 
 def synth_state_dict(encoder="vitl", features=256, out_channels=(256, 512, 1024, 1024), num_frames=32, seed=0,
-                     only=None):
+                     only=None, profile="smooth"):
     """Seeded synthetic weights as ``{key: np.float32 array}``; ``only`` restricts to keys with those prefixes.
 
-    Scales are chosen so activations stay O(1) through every layer, the four motion modules contribute
-    (their ``proj_out`` is *not* zero, unlike a freshly constructed reference module, motion_module.py:57-58)
-    and the final depth is positive with a moderate dynamic range.
+    Scales are chosen so activations stay O(1) through every layer and the four motion modules contribute
+    (their ``proj_out`` is *not* zero, unlike a freshly constructed reference module, motion_module.py:57-58).
+    ``profile`` selects the last 1x1 convolution (``output_conv2.2``), every other tensor is the same:
+      "smooth"   positive mixing weights and bias: the depth is positive with a moderate dynamic range, no pixel is
+                 near the final ReLU clamp;
+      "clamped"  mixed-sign mixing weights and a negative bias: a large share of the pixels is clamped to exactly 0
+                 and the positive ones reach down to the clamp (what a trained checkpoint gives: sky = 0), so errors
+                 are measured where the 32 hidden channels cancel.
     """
+    if profile not in ("smooth", "clamped"):
+        raise ValueError(profile)
     out = OrderedDict()
     for key, (shape, kind) in state_dict_spec(encoder, features, out_channels, num_frames).items():
         if only is not None and not any(key.startswith(p) for p in only):
@@ -169,6 +177,10 @@ def synth_state_dict(encoder="vitl", features=256, out_channels=(256, 512, 1024,
             v = sinusoid_table(shape[1], shape[2]).reshape(-1)
         elif kind == "b_out0":
             v = 0.5 + 0.1 * rs.standard_normal(n)
+        elif kind == "w_out2" and profile == "clamped":
+            v = rs.standard_normal(n) * (1.0 / math.sqrt(n))
+        elif kind == "b_out2" and profile == "clamped":
+            v = np.full(n, CLAMPED_PROFILE_BIAS)
         elif kind == "w_out2":     # positive mixing weights keep the depth away from the ReLU clamp
             v = np.abs(rs.standard_normal(n)) * (1.0 / math.sqrt(n)) + 0.02
         elif kind == "b_out2":

@@ -13,7 +13,7 @@ from . import hip
 from .engine import Engine
 from .packing import PackedWeights
 from .spec import ENCODERS, state_dict_spec
-from .windows import INFER_LEN, KEYFRAMES, OVERLAP, network_size, window_plan, Stitcher
+from .windows import INFER_LEN, KEYFRAMES, OVERLAP
 
 __all__ = ["VideoDepthAnything", "INFER_LEN", "OVERLAP", "KEYFRAMES"]
 

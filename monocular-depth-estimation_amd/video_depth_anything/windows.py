@@ -1,5 +1,5 @@
 """Host-side window logic of ``infer_video_depth``: network size rule, window composition with key-frame
-carry-over, rank partition of windows, and the affine stitch driven on the device.
+carry-over, rank partition of windows, and the affine alignment driven on the device.
 
 Reference: video_depth_anything/video_depth.py:30-33 (constants), 68-72 (aspect rule), 97-103 (padding), 112-132
 (window assembly), 166-209 (stitch); util/transform.py:51-107 (size rule); utils/util.py:40-74 (least squares, blend).
@@ -73,63 +73,53 @@ def resolve_plan(plan):
 
 
 def partition(n_windows, world, rank):
-    """Contiguous block of windows [lo, hi) for ``rank``: ceil(n/world) windows per rank."""
-    per = -(-n_windows // world)
-    lo = min(rank * per, n_windows)
-    return lo, min(lo + per, n_windows)
+    """The windows of ``rank``: window w runs on rank w % world, so that the windows of one round (world consecutive
+    windows) finish together and the sequential alignment can follow round by round."""
+    return list(range(rank, n_windows, world))
 
 
-class Stitcher:
-    """Sequential affine alignment + cross-fade of full windows, all arithmetic on the device.
+class Aligner:
+    """Sequential affine alignment of full windows, all arithmetic on the device (mirrors video_depth.py:169-205).
 
-    ``push(depth)`` takes one window's 32 raw maps ``[32, H0, W0]`` fp32 (in window order) and returns the list of maps that
-    became final.  Mirrors video_depth.py:169-205: window 0 passes through and provides the two reference key frames
-    (slots 0 and 12); a later window k is fitted ``s*d + t`` on its slots 0, 1 against the references, its slots 2..9 are
-    cross-faded onto the previous 8 aligned maps, slots 10..31 are appended, and the second reference becomes its
-    aligned slot 12.
+    ``advance(w, d0, d1, d12)`` takes the raw maps of slots 0, 1 and 12 of window w, in window order: window 0 provides the
+    two reference maps (its slots 0 and 12); a later window is fitted ``s*d + t`` on its slots 0, 1 against the references
+    and the second reference becomes its aligned slot 12.  Until the next ``advance``, ``apply`` aligns a raw map of that
+    window and ``blend`` cross-fades one of its slots 2..9 onto the previous window's aligned tail.  The fit never leaves
+    the device, so the host runs ahead of the GPU.
     """
 
     def __init__(self, device):
         self.dev = device
-        self.tail = None          # last 8 aligned maps (still open for blending)
         self.ref0 = None
         self.ref1 = None
         self.sums = torch.zeros(hip.LSQ_SUMS_DOUBLES, dtype=torch.float64, device=device)   # 5 totals + partial-sum scratch
         self.ss = torch.zeros(2, dtype=torch.float32, device=device)
-        self.started = False
+        self.window = -1
 
-    def _affine(self, x, pre=None, w_pre=0.0, w_post=1.0):
+    def advance(self, w, d0, d1, d12):
+        assert w == self.window + 1, "windows must be advanced in order"
+        self.window = w
+        if w == 0:
+            self.ref0, self.ref1 = d0.clone(), d12.clone()
+            return
+        self.sums.zero_()
+        hip.scale_shift_sums(d0.contiguous(), self.ref0, self.sums, d0.numel())
+        hip.scale_shift_sums(d1.contiguous(), self.ref1, self.sums, d1.numel())
+        hip.solve_scale_shift(self.sums, self.ss)
+        self.ref1 = self.apply(d12, w)
+
+    def apply(self, x, w, pre=None, w_pre=0.0, w_post=1.0):
+        """max(s*x + t, 0) with the current window's fit (window 0 is the reference frame of the video: unchanged)."""
+        assert w == self.window
+        if w == 0 and pre is None:
+            return x
         out = torch.empty_like(x)
-        hip.affine_blend(x, pre, out, self.ss, float(w_pre), float(w_post), x.numel())
+        hip.affine_blend(x.contiguous(), pre, out, self.ss, float(w_pre), float(w_post), x.numel())
         return out
 
-    def fit(self, d0, d1):
-        """Least-squares (scale, shift) of [d0, d1] onto [ref0, ref1]; stays on the device in ``self.ss``."""
-        self.sums.zero_()
-        hip.scale_shift_sums(d0, self.ref0, self.sums, d0.numel())
-        hip.scale_shift_sums(d1, self.ref1, self.sums, d1.numel())
-        hip.solve_scale_shift(self.sums, self.ss)
-
-    def push(self, depth):
-        assert depth.shape[0] == INFER_LEN
-        final = []
-        if not self.started:
-            self.started = True
-            self.ref0, self.ref1 = depth[0].clone(), depth[12].clone()
-            final = [depth[i] for i in range(INFER_LEN - INTERP_LEN)]
-            self.tail = [depth[i].clone() for i in range(INFER_LEN - INTERP_LEN, INFER_LEN)]
-            return final
-        self.fit(depth[0].contiguous(), depth[1].contiguous())
+    def blend(self, x, pre, i):
+        """Cross-fade of the current window's slot 2 + i (aligned) onto ``pre``, the previous window's aligned slot 24 + i,
+        with the weights of utils/util.py:67-73: 0, 1/7, ..., 6/7, 1 on the new window's side."""
         n = INTERP_LEN
-        for i in range(n):       # weights of utils/util.py:67-73: 0, 1/7, ..., 6/7, 1 on the new window's side
-            w_post = 0.0 if i == 0 else (1.0 if i == n - 1 else i * (1.0 / (n - 1)))
-            final.append(self._affine(depth[2 + i].contiguous(), self.tail[i], 1.0 - w_post, w_post))
-        for i in range(OVERLAP, INFER_LEN - INTERP_LEN):
-            final.append(self._affine(depth[i].contiguous()))
-        self.tail = [self._affine(depth[i].contiguous()) for i in range(INFER_LEN - INTERP_LEN, INFER_LEN)]
-        self.ref1 = self._affine(depth[12].contiguous())
-        return final
-
-    def flush(self):
-        t, self.tail = self.tail or [], None
-        return t
+        w_post = 0.0 if i == 0 else (1.0 if i == n - 1 else i * (1.0 / (n - 1)))
+        return self.apply(x, self.window, pre, 1.0 - w_post, w_post)

@@ -9,7 +9,7 @@ Weights come from the build's seeded generator (spec.synth_state_dict) and are l
 ``load_state_dict(strict=True)``; only inputs' seeds and the reference's outputs are stored.  While generating,
 the oracle restatement is checked against every reference output (fp32 vs fp32).
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py [--only-clamped]
 """
 import json
 import os
@@ -92,12 +92,46 @@ def synth_frames(n, h, w, seed):
     return out
 
 
+def clamped_profile_goldens(RefVDA):
+    """G4b / G5b: the forward pass and whole videos with the "clamped" weight profile (mixed-sign last 1x1 convolution:
+    16-45 % of the pixels are clamped to exactly 0 and the positive ones reach down to the clamp), so that parity is
+    also pinned where the output is a small difference of large terms."""
+    cfg = spec.MODEL_CONFIGS["vits"]
+    sd = to_torch(spec.synth_state_dict(**cfg, seed=1, profile="clamped"))
+    ref = RefVDA(**cfg).eval()
+    ref.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        g4 = {}
+        for name, shape, seed in (("T32", (1, 32, 3, 70, 98), 41), ("T4", (1, 4, 3, 70, 98), 42),
+                                  ("B2T3", (2, 3, 3, 56, 42), 43)):
+            x = torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32))
+            out = ref(x).numpy()
+            check(f"G4b forward {name}", O.forward(sd, x, "vits").numpy(), out)
+            g4[name] = out
+            pos = out[out > 0]
+            print(f"    depth range {out.min():.4f} .. {out.max():.4f}, zeros {np.mean(out == 0):.3f}, "
+                  f"max / smallest positive {out.max() / pos.min():.1e}")
+            assert np.mean(out == 0) >= 0.2 and out.max() / pos.min() >= 100
+        np.savez_compressed(os.path.join(GOLD, "g4b_forward_clamped.npz"), **g4)
+        g5 = {}
+        for n, bs in ((33, 32), (60, 32), (33, 16)):
+            frames = np.random.RandomState(700 + n).randint(0, 256, (n, 28, 42, 3)).astype(np.uint8)   # white noise
+            out, _ = ref.infer_video_depth(frames, 24, input_size=28, device="cpu", fp32=True, batch_size=bs)
+            check(f"G5b video N{n} bs{bs}", O.infer_video_depth(sd, list(frames), "vits", batch_size=bs), out)
+            print(f"    zeros {np.mean(out == 0):.3f}")
+            g5[f"N{n}_bs{bs}"] = out.astype(np.float32)
+        np.savez_compressed(os.path.join(GOLD, "g5b_video_clamped.npz"), **g5)
+
+
 def main():
     os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
     sys.dont_write_bytecode = True
     install_stubs()
     sys.path.insert(0, "/root/reference")
     from video_depth_anything.video_depth import VideoDepthAnything as RefVDA
+    if "--only-clamped" in sys.argv:      # add the G4b / G5b fixtures without rewriting the others
+        clamped_profile_goldens(RefVDA)
+        return
     from video_depth_anything.util.transform import Resize
     from video_depth_anything.dinov2_layers.block import Block as RefBlock
     from video_depth_anything.dinov2_layers.attention import MemEffAttention
@@ -251,6 +285,7 @@ def main():
         check("G7 F=256 fusion", O.fusion_block(big_sd, 2, a, b, size=(12, 10)).numpy(), out)
         g7["fusion"] = out
         np.savez_compressed(os.path.join(GOLD, "g7_vitl_width.npz"), **g7)
+    clamped_profile_goldens(RefVDA)
     print("goldens written to", GOLD)
     for f in sorted(os.listdir(GOLD)):
         print(f"  {f:28s} {os.path.getsize(os.path.join(GOLD, f)) / 1024:.0f} KiB")

@@ -56,9 +56,9 @@ def test_window_plan_matches_oracle_and_closed_form(n, bs):
 def test_partition_covers_all_windows():
     for n in (1, 5, 8, 9, 137):
         for world in (1, 2, 3, 8):
-            spans = [windows.partition(n, world, r) for r in range(world)]
-            assert spans[0][0] == 0 and spans[-1][1] == n
-            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            parts = [windows.partition(n, world, r) for r in range(world)]
+            assert sorted(w for p in parts for w in p) == list(range(n))
+            assert all(w % world == r for r, p in enumerate(parts) for w in p)      # round-robin: a round finishes together
 
 
 @pytest.mark.parametrize("enc", ["vits", "vitl"])
@@ -159,6 +159,13 @@ for n, bs in ((100, 32), (45, 32), (23, 32), (60, 16)):
     frames = T.frames_for(n, 28, 42, n)
     got, _ = pipeline.run_video(None, frames, 25, input_size=28, device="cpu", batch_size=bs, forward_fn=T.fake_forward)
     np.save(os.path.join({out!r}, f"r{{dist.get_rank()}}_{{n}}_{{bs}}.npy"), got)
+import types
+holder = types.SimpleNamespace()
+frames = T.frames_for(120, 28, 42, 120)
+got, _ = pipeline.run_video(holder, frames, 25, input_size=28, device="cpu", batch_size=32, forward_fn=T.fake_forward, shard_output="local")
+np.save(os.path.join({out!r}, f"local{{dist.get_rank()}}.npy"), got)
+np.save(os.path.join({out!r}, f"owned{{dist.get_rank()}}.npy"), holder.last_owned_frames)
+assert holder.last_shard_stats["gathered_bytes_per_round"] == dist.get_world_size() * 11 * 28 * 42 * 4
 dist.barrier()
 """
 
@@ -182,3 +189,10 @@ def test_window_sharded_pipeline_over_gloo_matches_single_process(tmp_path, worl
             got = np.load(tmp_path / f"r{r}_{n}_{bs}.npy")
             assert got.shape == want.shape
             assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), (n, bs, r)
+    # shard_output="local": disjoint parts that cover the video; eleven maps per rank and round are exchanged, no final frame
+    want = O.infer_video_depth(None, list(frames_for(120, 28, 42, 120)), "vits", batch_size=32, forward_fn=fake_forward)
+    masks = np.stack([np.load(tmp_path / f"owned{r}.npy") for r in range(world)])
+    assert (masks.sum(0) == 1).all()
+    for r in range(world):
+        got = np.load(tmp_path / f"local{r}.npy")
+        assert np.abs(got[masks[r]] - want[masks[r]]).max() <= 2e-5 * np.abs(want).max() and not got[~masks[r]].any()

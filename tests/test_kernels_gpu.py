@@ -39,7 +39,9 @@ BF_OUT = 6e-3      # bf16 output rounding (2^-8 worst case incl. accumulation no
 F32_OUT = 2e-5
 STORAGE = HALVES + [torch.float32]          # activation storage types: 16-bit modes and the fp32 mode
 OUT_TOL = {torch.bfloat16: BF_OUT, torch.float16: BF_OUT, torch.float32: F32_OUT}
-SPLIT_TOL = 6e-5   # three-term bf16 hi/lo product: 2^-16 per operand pair, relative to the largest output
+# three-term hi/lo product, relative to the largest output: bf16 pieces 2^-16 per operand pair; IEEE-half pieces 2^-21,
+# where the bound is set by the fp32 accumulation over K
+SPLIT_TOL = {torch.bfloat16: 6e-5, torch.float16: 2e-6}
 
 
 def test_library_loads_and_reports_version():
@@ -456,39 +458,60 @@ def test_stitch_kernels():
     assert torch.allclose(out, torch.clamp(x * ss[0] + ss[1], min=0), rtol=1e-6, atol=1e-6)
 
 
-def split_w(w):
-    from video_depth_anything.packing import split_weight
-    return split_weight(w)
+def split_w(w, piece):
+    from video_depth_anything.packing import SplitWeight
+    return SplitWeight(w, piece)
 
 
+ACT_SCALE = {torch.bfloat16: 1.0, torch.float16: 16.0}     # what the engine multiplies activations by before the split
+
+
+@pytest.mark.parametrize("piece", HALVES)
 @pytest.mark.parametrize("rows,C,Cp,relu", [(1000, 256, 256, False), (37, 48, 64, True), (5, 640, 640, False)])
-def test_split3_layout_and_accuracy(rows, C, Cp, relu):
+def test_split3_layout_and_accuracy(rows, C, Cp, relu, piece):
     x = rnd((rows, C + 4), 1, 3.0, torch.float32)[:, :C]                  # row stride larger than C
-    out = torch.full((rows, 3 * Cp), float("nan"), dtype=BF, device=DEV)
-    hip.split3(x, out, rows, C, x.stride(0), Cp, relu=relu)
-    ref = F.relu(x) if relu else x
+    out = torch.full((rows, 3 * Cp), float("nan"), dtype=piece, device=DEV)
+    sc = ACT_SCALE[piece]
+    hip.split3(x, out, rows, C, x.stride(0), Cp, relu=relu, scale=sc)
+    ref = (F.relu(x) if relu else x) * sc
     hi, lo, hi2 = out[:, :C].float(), out[:, Cp:Cp + C].float(), out[:, 2 * Cp:2 * Cp + C].float()
-    assert torch.equal(hi, ref.to(BF).float()) and torch.equal(hi, hi2)
-    assert torch.equal(lo, (ref - hi).to(BF).float())
-    assert ((hi + lo) - ref).abs().max() <= 2.0 ** -16 * ref.abs().max()
+    assert torch.equal(hi, ref.to(piece).float()) and torch.equal(hi, hi2)
+    assert torch.equal(lo, (ref - hi).to(piece).float())
+    if piece == BF:
+        assert ((hi + lo) - ref).abs().max() <= 2.0 ** -16 * ref.abs().max()
+    else:       # 2^-22 relative while the low half is a normal number, 2^-25 absolute below
+        assert (((hi + lo) - ref).abs() <= 2.0 ** -22 * ref.abs() + 2.0 ** -25).all()
     for seg in range(3):
         assert torch.count_nonzero(out[:, seg * Cp + C:(seg + 1) * Cp]) == 0
 
 
+def test_split3_half_pieces_saturate_instead_of_overflowing():
+    x = torch.tensor([[1e6, -1e6, 70000.0, 3.0]], dtype=torch.float32, device=DEV)
+    out = torch.empty((1, 3 * 64), dtype=torch.float16, device=DEV)
+    hip.split3(x, out, 1, 4, 4, 64, scale=1.0)
+    assert torch.isfinite(out.float()).all()
+    assert out[0, 0].item() == 65504.0 and out[0, 1].item() == -65504.0
+    assert out[0, 2].item() + out[0, 64 + 2].item() == 70000.0        # the low half takes up the excess
+
+
+@pytest.mark.parametrize("piece", HALVES)
 @pytest.mark.parametrize("cfg", TILE_CFGS)
 @pytest.mark.parametrize("M,N,K", [(1370, 1024, 1024), (300, 192, 384)])
-def test_gemm_fp32_mode_three_term_product(M, N, K, cfg):
-    """fp32 operands through vda_split3 / split weights: close to an fp64 product, ~100x closer than one bf16 pass."""
+def test_gemm_fp32_mode_three_term_product(M, N, K, cfg, piece):
+    """fp32 operands through vda_split3 / split weights: close to an fp64 product, ~100x (bf16 pieces) or ~3000x (IEEE-half
+    pieces, operands scaled by powers of two and the sums scaled back) closer than one 16-bit pass."""
     a, w = rnd((M, K), 1, 1.0, torch.float32), rnd((N, K), 2, 1 / math.sqrt(K), torch.float32)
     bias = rnd((N,), 3, 0.1, torch.float32)
-    a3 = torch.empty((M, 3 * K), dtype=BF, device=DEV)
-    hip.split3(a, a3, M, K, K, K)
+    a3 = torch.empty((M, 3 * K), dtype=piece, device=DEV)
+    hip.split3(a, a3, M, K, K, K, scale=ACT_SCALE[piece])
     out = torch.empty((M, N), dtype=torch.float32, device=DEV)
-    hip.gemm(a3, split_w(w), out, M=M, N=N, K=3 * K, lda=3 * K, ldc=N, bias=bias, tile_cfg=cfg)
+    sw = split_w(w, piece)
+    kw = dict(M=M, N=N, K=3 * K, lda=3 * K, ldc=N, bias=bias, tile_cfg=cfg, acc_scale=1.0 / (sw.scale * ACT_SCALE[piece]))
+    hip.gemm(a3, sw.t, out, **kw)
     want = (a.double() @ w.double().t() + bias.double()).float()
-    close(out, want, SPLIT_TOL, "three-term gemm")
+    close(out, want, SPLIT_TOL[piece], "three-term gemm")
     with pytest.raises(RuntimeError):            # the epilogue's GELU is for 16-bit outputs; fp32 callers use vda_split3's
-        hip.gemm(a3, split_w(w), out, M=M, N=N, K=3 * K, lda=3 * K, ldc=N, bias=bias, act=hip.ACT_GELU, tile_cfg=cfg)
+        hip.gemm(a3, sw.t, out, act=hip.ACT_GELU, **kw)
 
 
 def test_split3_gelu_and_geglu_are_exact_form():
@@ -502,6 +525,10 @@ def test_split3_gelu_and_geglu_are_exact_form():
     want = F.gelu(x.double()).float()
     assert (got - want).abs().max() <= 2e-6 * want.abs().max() + 2.0 ** -16 * want.abs().max()
     assert torch.equal(out[:, :C], out[:, 2 * C:])
+    half = torch.empty((rows, 3 * C), dtype=torch.float16, device=DEV)
+    hip.split3(x, half, rows, C, C, C, act=hip.SPLIT_GELU, scale=16.0)
+    got = (half[:, :C].float() + half[:, C:2 * C].float()) / 16.0
+    assert (got - want).abs().max() <= 1e-6 * want.abs().max()
     xg = rnd((rows, 2 * C), 2, 2.0, torch.float32)
     hip.split3(xg, out, rows, C, 2 * C, C, act=hip.SPLIT_GEGLU)
     blocks = xg.reshape(rows, C // 16, 2, 16)
@@ -525,19 +552,21 @@ def test_gemm_gelu_polynomial_accuracy():
         assert (err <= 5.4e-5 + 2.0 ** -11 * want.abs() + 1e-7).all(), err.max()
 
 
-def test_conv3x3_fp32_mode():
+@pytest.mark.parametrize("piece", HALVES)
+def test_conv3x3_fp32_mode(piece):
     B, h, w_, cin, cout = 2, 19, 13, 64, 128
     x = rnd((B, cin, h, w_), 1, 1.0, torch.float32)
     wt = rnd((cout, cin, 3, 3), 2, 1 / math.sqrt(9 * cin), torch.float32)
     bias = rnd((cout,), 3, 0.1, torch.float32)
     want = F.conv2d(F.relu(x).double(), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1).float()
     a = x.permute(0, 2, 3, 1).contiguous().reshape(B * h * w_, cin)
-    a3 = torch.empty((B * h * w_, 3 * cin), dtype=BF, device=DEV)
-    hip.split3(a, a3, B * h * w_, cin, cin, cin, relu=True)
-    wg = split_w(wt.permute(0, 2, 3, 1).contiguous()).reshape(cout, 27 * cin)
+    a3 = torch.empty((B * h * w_, 3 * cin), dtype=piece, device=DEV)
+    hip.split3(a, a3, B * h * w_, cin, cin, cin, relu=True, scale=ACT_SCALE[piece])
+    wg = split_w(wt.permute(0, 2, 3, 1).contiguous(), piece).reshape(cout, 27 * cin)
     out = torch.empty((B, h, w_, cout), dtype=torch.float32, device=DEV)
-    hip.gemm(a3, wg, out, M=B * h * w_, N=cout, K=27 * cin, lda=0, ldc=cout, bias=bias, conv=(h, w_, 3 * cin, h, w_, 1))
-    close(out, want, SPLIT_TOL, "three-term conv3x3")
+    hip.gemm(a3, wg.t, out, M=B * h * w_, N=cout, K=27 * cin, lda=0, ldc=cout, bias=bias, conv=(h, w_, 3 * cin, h, w_, 1),
+             acc_scale=1.0 / (wg.scale * ACT_SCALE[piece]))
+    close(out, want, SPLIT_TOL[piece], "three-term conv3x3")
 
 
 @pytest.mark.parametrize("frames,n_tok,heads", [(2, 1370, 2), (1, 129, 3), (2, 36, 1)])
@@ -549,7 +578,7 @@ def test_attention_fp32_mode(frames, n_tok, heads):
     hip.attention(qkv, out, frames, n_tok, heads)
     q, k, v = qkv.double().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
     want = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(frames, n_tok, D).float()
-    close(out, want, 2e-4, "attention, fp32 mode")
+    close(out, want, 3e-6, "attention, fp32 mode")
 
 
 def test_rejected_arguments_return_error_codes():

@@ -131,3 +131,19 @@ def test_cubic_resize_restatement_properties():
     assert np.abs(half[:, 1:-1, 0] - (np.arange(8)[1:-1] * 2 + 0.5)).max() < 1e-5
     frame = rs.randint(0, 256, (10, 14, 3), dtype=np.uint8)
     assert np.array_equal(O.preprocess_frame(frame, 10, 14), O.normalize_frame(frame))
+
+
+def test_clamped_profile_forward_and_video(golden_dir):
+    """Depth maps with exact zeros (mixed-sign last 1x1 convolution): forward goldens G4b and whole-video goldens G5b."""
+    sdc = {k: torch.from_numpy(v) for k, v in spec.synth_state_dict(**spec.MODEL_CONFIGS["vits"], seed=1, profile="clamped").items()}
+    g = np.load(os.path.join(golden_dir, "g4b_forward_clamped.npz"))
+    for name, shape, seed in (("T4", (1, 4, 3, 70, 98), 42), ("B2T3", (2, 3, 3, 56, 42), 43)):
+        x = torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32))
+        out = O.forward(sdc, x, "vits").numpy()
+        assert rel(out, g[name]) < TOL and np.mean(g[name] == 0) >= 0.2
+        assert np.mean((out == 0) != (g[name] == 0)) < 1e-3
+    g = np.load(os.path.join(golden_dir, "g5b_video_clamped.npz"))
+    for n, bs in ((33, 32), (33, 16)):
+        frames = np.random.RandomState(700 + n).randint(0, 256, (n, 28, 42, 3)).astype(np.uint8)
+        out = O.infer_video_depth(sdc, list(frames), "vits", batch_size=bs)
+        assert rel(out, g[f"N{n}_bs{bs}"]) < TOL and np.mean(out == 0) >= 0.1
