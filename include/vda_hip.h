@@ -132,6 +132,16 @@ int vda_layernorm(const float* x, void* out, const float* weight, const float* b
 int vda_groupnorm(const void* x, void* out, const float* weight, const float* bias, void* work, int frames, int hw,
                   int C, int groups, float eps, int dtype, void* stream);
 
+/* vda_groupnorm without the `work` argument, for callers that cannot allocate device memory (code under HIP graph capture,
+ * serving loops with a fixed memory plan): the partial sums live in a 4 MiB device array inside this library, one copy per
+ * GPU, held until the process ends.  No counterpart in the reference.  Same results as vda_groupnorm, bit for bit.
+ * frames <= VDA_GROUPNORM_STATIC_MAX_FRAMES, else VDA_ESHAPE.  The device that `stream` belongs to must be the current
+ * device.  Calls on one GPU share the array: two calls that may run at the same time (different streams) race; calls on
+ * one stream, or otherwise ordered, are safe, and nothing needs clearing between them.  Allocates nothing. */
+#define VDA_GROUPNORM_STATIC_MAX_FRAMES 64
+int vda_groupnorm_static(const void* x, void* out, const float* weight, const float* bias, int frames, int hw, int C,
+                         int groups, float eps, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Bilinear resampling with align_corners=True (src = dst * (in-1)/(out-1)).
  * vda_bilinear_nhwc: [frames][in_h][in_w][C] -> [frames][out_h][out_w][C] of dtype BF16, F16 or F32   (util/blocks.py:156-158,

@@ -2,6 +2,7 @@
 // Every global access is a 16-byte (LayerNorm) or 8/16-byte (GroupNorm) vector per lane; statistics are two-pass in
 // registers (LayerNorm) or fp32 partials combined in double (GroupNorm).
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -167,6 +168,46 @@ extern "C" int vda_layernorm(const float* x, void* out, const float* weight, con
     else LN_LAUNCH(8);
 #undef LN_LAUNCH
     return hip_rc(hipGetLastError());
+}
+
+// ---- vda_groupnorm_static: the same two passes with the partial sums in a device array of this library ------------------------
+// [frame][split][group][2] doubles at the maximum of every extent: 4 MiB per GPU, held from the library's first use of that
+// GPU until the process ends.  The array's name is only a handle on the host: kernels get the address that
+// hipGetSymbolAddress returns for the CURRENT device, looked up once per device and kept.
+constexpr int GN_STATIC_MAX_GROUPS = 64;
+static __device__ __align__(256) double gn_scratch[VDA_GROUPNORM_STATIC_MAX_FRAMES * VDA_GROUPNORM_MAX_SPLITS * GN_STATIC_MAX_GROUPS * 2];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex gn_mutex;
+double* gn_scratch_ptr[MAX_DEVICES];       // per device: device address of gn_scratch, nullptr until looked up
+
+int gn_scratch_for_current_device(double** ptr) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_rc(e);
+    if (dev < 0 || dev >= MAX_DEVICES) return VDA_ESHAPE;
+    std::lock_guard<std::mutex> lock(gn_mutex);
+    if (!gn_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(gn_scratch));
+        if (e != hipSuccess) return hip_rc(e);
+        if (!p) return VDA_EINVAL;
+        gn_scratch_ptr[dev] = static_cast<double*>(p);
+    }
+    *ptr = gn_scratch_ptr[dev];
+    return VDA_OK;
+}
+}  // namespace
+
+extern "C" int vda_groupnorm_static(const void* x, void* out, const float* weight, const float* bias, int frames, int hw,
+                                    int C, int groups, float eps, int dtype, void* stream) {
+    if (frames > VDA_GROUPNORM_STATIC_MAX_FRAMES) return VDA_ESHAPE;       // the scratch array holds 64 frames' partial sums
+    double* work = nullptr;
+    const int rc = gn_scratch_for_current_device(&work);
+    if (rc != VDA_OK) return rc;
+    // every partial sum pass 2 reads is written by pass 1 of the same call: nothing has to be cleared between calls
+    return vda_groupnorm(x, out, weight, bias, work, frames, hw, C, groups, eps, dtype, stream);
 }
 
 extern "C" int vda_groupnorm(const void* x, void* out, const float* weight, const float* bias, void* work, int frames,

@@ -20,7 +20,7 @@ GROUPNORM_MAX_SPLITS = 64        # VDA_GROUPNORM_MAX_SPLITS: sizes the scratch o
 LSQ_SUMS_DOUBLES = 5 + 4 * 256   # VDA_LSQ_SUMS_DOUBLES: five totals + per-workgroup partials of scale_shift_sums()
 
 EXPORTS = [
-    "vda_version", "vda_gemm", "vda_attention", "vda_layernorm", "vda_groupnorm", "vda_bilinear_nhwc", "vda_bilinear_f32",
+    "vda_version", "vda_gemm", "vda_attention", "vda_layernorm", "vda_groupnorm", "vda_groupnorm_static", "vda_bilinear_nhwc", "vda_bilinear_f32",
     "vda_im2col_patch14", "vda_assemble_tokens", "vda_temporal_attention", "vda_scale_shift_sums", "vda_solve_scale_shift",
     "vda_affine_blend", "vda_preprocess_u8", "vda_split3",
 ]
@@ -58,6 +58,8 @@ def lib():
                                     C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.vda_groupnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_float, C.c_int, C.c_void_p]
+        l.vda_groupnorm_static.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_float, C.c_int, C.c_void_p]
         l.vda_bilinear_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
         l.vda_bilinear_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         l.vda_im2col_patch14.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -228,6 +230,16 @@ def groupnorm(x, out, weight, bias, work, frames, hw, Cdim, groups, eps):
     _dev(x, out, weight, bias, work)
     _check(lib().vda_groupnorm(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(work), frames, hw, Cdim, groups, eps,
                                _type(x), _stream()), "vda_groupnorm")
+
+
+GROUPNORM_STATIC_MAX_FRAMES = 64     # VDA_GROUPNORM_STATIC_MAX_FRAMES
+
+
+def groupnorm_static(x, out, weight, bias, frames, hw, Cdim, groups, eps):
+    """vda_groupnorm with the library's own scratch array (no workspace, no allocation); the tensors' device must be current."""
+    _dev(x, out, weight, bias)
+    _check(lib().vda_groupnorm_static(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), frames, hw, Cdim, groups, eps, _type(x),
+                                      _stream()), "vda_groupnorm_static")
 
 
 def bilinear_nhwc(x, out, frames, in_h, in_w, out_h, out_w, Cdim):
