@@ -99,6 +99,11 @@ typedef struct VdaGemmArgs {
 
 int vda_gemm(const VdaGemmArgs* args, void* stream);
 
+/* Which kernel vda_gemm runs for these arguments (it launches nothing): a VDA_KERNEL_* code, or the negative error code
+ * vda_gemm would return.  For profiling tools that attribute a launch to its kernel. */
+enum { VDA_KERNEL_128x32 = 0, VDA_KERNEL_128x64 = 1, VDA_KERNEL_128x128 = 2, VDA_KERNEL_256x256 = 3, VDA_KERNEL_CONV_DIRECT = 4 };
+int vda_gemm_kernel_choice(const VdaGemmArgs* args);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Multi-head self-attention over the tokens of each frame, head dim 64, no mask, flash-style (scores never leave
  * the CU).  qkv: [frames][n_tok][3*heads*64] laid out [q | k | v] x [head][64] as produced by the fused QKV

@@ -170,7 +170,10 @@ int launch(const VdaGemmArgs& a, hipStream_t s) {
 }  // namespace
 }  // namespace vda
 
-extern "C" int vda_gemm(const VdaGemmArgs* args, void* stream) {
+namespace {
+
+// argument checks of vda_gemm: VDA_OK or the error code
+int check_args(const VdaGemmArgs* args) {
     using namespace vda;
     if (!args || !args->a || !args->w || !args->out) return VDA_EINVAL;
     const VdaGemmArgs& a = *args;
@@ -204,20 +207,25 @@ extern "C" int vda_gemm(const VdaGemmArgs* args, void* stream) {
     if ((a.act == VDA_ACT_GELU || a.epi == VDA_EPI_GEGLU) && a.out_type == VDA_T_F32) return VDA_ESHAPE;
     if (a.ab_type != VDA_T_BF16 && a.ab_type != VDA_T_F16) return VDA_EINVAL;
     if (a.tile_cfg < 0 || a.tile_cfg > 3) return VDA_EINVAL;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return VDA_OK;
+}
+
+// which kernel vda_gemm runs for checked arguments: a VDA_KERNEL_* code, or a negative error code
+int choose_kernel(const VdaGemmArgs& a) {
+    using namespace vda;
     // 3x3 convolutions: the direct kernel copies each input pixel once per patch and channel slice instead of once per tap.
     // Narrow outputs (N <= 128) always gain (1.3x at N = 128, 1.8x at N = 32); wide ones only while the 8 x 32 patches
     // cover the image well (148 x 148: 90 % covered, +10 %; 74 x 74: 71 %, -4 % against the 256x256 tile).
     if (a.a_mode == VDA_A_CONV3 && a.up_h > 0)       // fused upsampling exists in the direct kernel only
-        return ((a.tile_cfg == 0 || a.tile_cfg == 3) && conv_direct_supports(a)) ? launch_conv_direct(a, s) : VDA_ESHAPE;
+        return ((a.tile_cfg == 0 || a.tile_cfg == 3) && conv_direct_supports(a)) ? VDA_KERNEL_CONV_DIRECT : VDA_ESHAPE;
     if ((a.tile_cfg == 0 || a.tile_cfg == 3) && conv_direct_supports(a)) {
         const long ty = (a.out_h + 7) / 8, tx = (a.out_w + 31) / 32;
         const long patches = (long)(a.M / (a.out_h * a.out_w)) * ty * tx;
         const bool covered = (long)a.out_h * a.out_w * 100 >= ty * 8 * tx * 32 * 88;
-        if (a.tile_cfg == 3 || (patches >= 512 && (a.N <= 128 || covered))) return launch_conv_direct(a, s);
+        if (a.tile_cfg == 3 || (patches >= 512 && (a.N <= 128 || covered))) return VDA_KERNEL_CONV_DIRECT;
     }
-    if (a.N <= 32) return launch<128, 32, 4, 1>(a, s);
-    if (a.N <= 64) return launch<128, 64, 2, 2>(a, s);
+    if (a.N <= 32) return VDA_KERNEL_128x32;
+    if (a.N <= 64) return VDA_KERNEL_128x64;
     // The 256x256 pipelined kernel moves half as many bytes global -> LDS per MFMA as the 128x128 one, which is what bounds
     // the latter (about 30 B/clk/CU of copy throughput on either); but it runs one workgroup per CU, so nothing overlaps a
     // tile's prologue and its output stores.  It wins once the K loop amortises those or the grid is many rounds deep
@@ -231,6 +239,28 @@ extern "C" int vda_gemm(const VdaGemmArgs* args, void* stream) {
     const bool wide = a.N >= 192 && 5 * a.N >= 4 * 256 * ((a.N + 255) / 256);
     const bool fills = a.K >= 1024 ? tiles256 >= 160 : a.K >= 512 ? tiles256 >= 1024 : a.K >= 256 && tiles256 >= 1800;
     const bool big = a.tile_cfg == 2 || (a.tile_cfg == 0 && wide && fills);
-    if (big) return launch_gemm256(a, s);
-    return launch<128, 128, 2, 2>(a, s);
+    return big ? VDA_KERNEL_256x256 : VDA_KERNEL_128x128;
+}
+
+}  // namespace
+
+extern "C" int vda_gemm_kernel_choice(const VdaGemmArgs* args) {
+    const int rc = check_args(args);
+    return rc != VDA_OK ? rc : choose_kernel(*args);
+}
+
+extern "C" int vda_gemm(const VdaGemmArgs* args, void* stream) {
+    using namespace vda;
+    const int rc = check_args(args);
+    if (rc != VDA_OK) return rc;
+    const VdaGemmArgs& a = *args;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (choose_kernel(a)) {
+        case VDA_KERNEL_CONV_DIRECT: return launch_conv_direct(a, s);
+        case VDA_KERNEL_128x32: return launch<128, 32, 4, 1>(a, s);
+        case VDA_KERNEL_128x64: return launch<128, 64, 2, 2>(a, s);
+        case VDA_KERNEL_256x256: return launch_gemm256(a, s);
+        case VDA_KERNEL_128x128: return launch<128, 128, 2, 2>(a, s);
+        default: return VDA_ESHAPE;
+    }
 }

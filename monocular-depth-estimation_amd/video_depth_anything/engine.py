@@ -32,6 +32,8 @@ class Engine:
         self.hdt = packed.head_dtype         # storage/operand type of the DPT head and the temporal modules
         self.edt = torch.float32 if self.split else BF16      # storage type of the encoder's GEMM operands
         self.act_scale = ACT_SPLIT_SCALE if SPLIT_DTYPE == torch.float16 else 1.0
+        self.encoder_streams = 2      # frame groups of the encoder that run on concurrent streams (see encoder())
+        self.side_streams = []
 
     # ---- small wrappers -------------------------------------------------------------------------------------------
     def operand(self, a, relu=False, act=None):
@@ -98,8 +100,44 @@ class Engine:
 
     # ---- encoder (reference: dinov2.py:212-231, 271-281, 297-321; block.py:82-107) --------------------------------------
     def encoder(self, x, frames, H, W):
+        """The four tapped, normalised token maps [frames * hw, D].  The encoder treats every frame on its own, so the frames
+        are split into ``self.encoder_streams`` groups that run on separate HIP streams: while one group's workgroups drain
+        at the end of a kernel (a GEMM grid rarely fills its last round of tiles) or wait on HBM (LayerNorm, residual
+        epilogues), the other group's matrix-bound kernels take the idle CUs.  Same kernels on the same rows: same bits."""
+        w, dev = self.w, self.dev
+        hw = (H // 14) * (W // 14)
+        taps = [_empty((frames * hw, w.D), self.hdt, dev) for _ in w.taps]
+        w.pos_table(H // 14, W // 14)             # built (and uploaded) on this stream before any other stream reads it
+        groups = min(self.encoder_streams, frames)
+        if groups <= 1:
+            self.encoder_frames(x, 0, frames, H, W, taps)
+            return taps
+        main = torch.cuda.current_stream()
+        if len(self.side_streams) < groups - 1:
+            self.side_streams += [torch.cuda.Stream(device=dev) for _ in range(groups - 1 - len(self.side_streams))]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        bounds = [frames * g // groups for g in range(groups + 1)]
+        joins = []
+        for g in range(1, groups):
+            side = self.side_streams[g - 1]
+            side.wait_event(fork)                     # x and the tap buffers exist
+            with torch.cuda.stream(side):
+                self.encoder_frames(x, bounds[g], bounds[g + 1], H, W, taps)
+                done = torch.cuda.Event()
+                done.record(side)
+            joins.append(done)
+        self.encoder_frames(x, bounds[0], bounds[1], H, W, taps)
+        for done in joins:
+            main.wait_event(done)
+        return taps
+
+    def encoder_frames(self, x, f0, f1, H, W, taps):
+        """Frames f0..f1-1 through the encoder on the current stream; writes their rows of the tap buffers."""
         w, dev = self.w, self.dev
         D, heads = w.D, w.heads
+        frames = f1 - f0
+        x = x[f0:f1]
         hp, wp = H // 14, W // 14
         hw, N = hp * wp, hp * wp + 1
         M = frames * N
@@ -114,7 +152,7 @@ class Engine:
         qkv = _empty((M, 3 * D), self.edt, dev)
         att = _empty((M, D), self.edt, dev)
         hid = _empty((M, 4 * D), self.edt, dev)
-        taps = []
+        tap = 0
         for i, b in enumerate(w.blocks):
             hip.layernorm(xs, y, b["ln1_w"], b["ln1_b"], M, D, 1e-6)
             self.linear(y, b["wqkv"], qkv, b["bqkv"])
@@ -128,10 +166,9 @@ class Engine:
                 self.linear(y, b["wfc1"], hid, b["bfc1"], act=hip.ACT_GELU)
                 self.linear(hid, b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D)
             if i in w.taps:
-                t = _empty((frames * hw, D), self.hdt, dev)
+                t = taps[tap][f0 * hw:f1 * hw]
+                tap += 1
                 hip.layernorm(xs, t, w.norm_w, w.norm_b, frames * hw, D, 1e-6, rows_per_group=hw, in_group=N, in_skip=1)
-                taps.append(t)
-        return taps
 
     # ---- temporal module (reference: motion_module.py:102-126, 164-177, 230-297) ----------------------------------------
     def motion(self, idx, x, B, T):

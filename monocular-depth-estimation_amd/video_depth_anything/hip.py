@@ -20,7 +20,7 @@ GROUPNORM_MAX_SPLITS = 64        # VDA_GROUPNORM_MAX_SPLITS: sizes the scratch o
 LSQ_SUMS_DOUBLES = 5 + 4 * 256   # VDA_LSQ_SUMS_DOUBLES: five totals + per-workgroup partials of scale_shift_sums()
 
 EXPORTS = [
-    "vda_version", "vda_gemm", "vda_attention", "vda_layernorm", "vda_groupnorm", "vda_groupnorm_static", "vda_bilinear_nhwc", "vda_bilinear_f32",
+    "vda_version", "vda_gemm", "vda_gemm_kernel_choice", "vda_attention", "vda_layernorm", "vda_groupnorm", "vda_groupnorm_static", "vda_bilinear_nhwc", "vda_bilinear_f32",
     "vda_im2col_patch14", "vda_assemble_tokens", "vda_temporal_attention", "vda_scale_shift_sums", "vda_solve_scale_shift",
     "vda_affine_blend", "vda_preprocess_u8", "vda_split3",
 ]
@@ -53,6 +53,7 @@ def lib():
         l = C.CDLL(LIB_PATH)
         l.vda_version.restype = C.c_char_p
         l.vda_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+        l.vda_gemm_kernel_choice.argtypes = [C.POINTER(GemmArgs)]
         l.vda_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.vda_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
                                     C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -153,8 +154,9 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
     if convt is not None:
         g.ct_h, g.ct_w, g.ct_k, g.ct_c = convt
     t = _gemm_timing
-    if t is not None and conv is None and g.ab_type == T_BF16 and N >= 192 and K >= 1024 and epi == EPI_PLAIN and gamma is None:
-        # which instantiation of the 256x256 kernel this launch takes (its epilogue form)
+    if t is not None and conv is None and epi == EPI_PLAIN and gamma is None:
+        # the kernel the library picks for this launch, and the epilogue form (= kernel instantiation) it takes
+        kernel = KERNEL_NAMES.get(lib().vda_gemm_kernel_choice(C.byref(g)), "?")
         if resid is not None and resid.dtype == torch.float32 and out.dtype == torch.float32 and act == ACT_NONE and resid2 is None:
             form = "f32_res32"
         elif resid is None and out.dtype == a.dtype:
@@ -165,24 +167,32 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
         e0.record()
         _check(lib().vda_gemm(C.byref(g), _stream()), "vda_gemm")
         e1.record()
-        t.events.append((e0, e1, 2.0 * M * N * K, form))
+        t.events.append((e0, e1, 2.0 * M * N * K, (kernel, form, _TYPE_NAMES[g.ab_type])))
         return
     _check(lib().vda_gemm(C.byref(g), _stream()), "vda_gemm")
 
 
+KERNEL_NAMES = {0: "gemm_kernel<128,32>", 1: "gemm_kernel<128,64>", 2: "gemm_kernel<128,128>", 3: "gemm256_kernel", 4: "conv3_direct_kernel"}
+_TYPE_NAMES = {T_BF16: "bf16", T_F16: "f16"}
+
+
 class GemmTiming:
-    """Per-launch HIP-event timing of the 256x256-tile bf16 linear GEMMs (the encoder's qkv / proj / fc1 / fc2 products; the
-    shape test above mirrors vda_gemm's choice of that kernel), tagged by the epilogue form = kernel instantiation they
-    take: "f32_res32" (proj, fc2), "own_gelu" (fc1), "own" (qkv).  The events are recorded on the stream the kernel is
-    launched on (torch's current stream)."""
+    """Per-launch HIP-event timing of the plain linear GEMMs, tagged (kernel, epilogue form, operand type): the kernel is the
+    one the library reports for the launch (vda_gemm_kernel_choice), the form is the kernel instantiation the epilogue
+    takes: "f32_res32" (proj, fc2), "own_gelu" (fc1), "own" (qkv and others).  The events are recorded on the stream the
+    kernel is launched on (torch's current stream); launches on concurrent streams overlap and cannot be told apart this
+    way, so time with one stream."""
 
     def __init__(self):
         self.events = []
 
-    def summary(self, form=None):
-        """(launches, total algorithmic FLOP, total milliseconds) of one form or of all; call after a device synchronize."""
-        ev = [e for e in self.events if form is None or e[3] == form]
+    def summary(self, tag=None):
+        """(launches, total algorithmic FLOP, total milliseconds) of one tag or of all; call after a device synchronize."""
+        ev = [e for e in self.events if tag is None or e[3] == tag]
         return len(ev), sum(e[2] for e in ev), sum(e[0].elapsed_time(e[1]) for e in ev)
+
+    def tags(self):
+        return sorted({e[3] for e in self.events})
 
 
 _gemm_timing = None

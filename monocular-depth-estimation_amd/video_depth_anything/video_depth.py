@@ -5,6 +5,8 @@ metric_depth/video_depth_anything/video_depth.py:67-270), computed by hand-writt
 There is no CPU or eager-PyTorch path: ``forward`` raises if the module or the input is not on a ROCm device or the
 kernel library is not built.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -73,12 +75,31 @@ class VideoDepthAnything(nn.Module):
             else:
                 t = torch.empty(shape).normal_(0.0, 0.02, generator=gen)
             _install(self, key, t, buffer=(kind == "pe"))
+        # frame groups of the encoder that run on concurrent HIP streams (see Engine.encoder)
+        self.encoder_streams = int(os.environ.get("VDA_ENCODER_STREAMS", "2"))
+        # multi-rank infer_video_depth: "replicate" = every rank returns the whole video, "local" = a rank returns only the
+        # frames of its own windows (zeros elsewhere; ``last_owned_frames`` is the mask) and no final frame is exchanged
+        self.shard_output = "replicate"
         self._engines = {}            # precision -> (weights key, Engine)
+        self._flat = None             # the parameter and buffer tensors, listed once (see _weights_key)
 
     # ---- weights -> kernel layouts, rebuilt whenever the parameters change or move -----------------------------------
+    def _apply(self, fn, *a, **kw):               # .to() / .cuda() / .float() replace buffers and parameter storage
+        self._flat = None
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._flat = None
+        return super().load_state_dict(*a, **kw)
+
     def _weights_key(self):
+        """Identity of the current weights: (address, in-place version) of every tensor.  The tensor list itself is cached
+        (walking the module tree costs more than a ViT-S window's launch overhead can spare) and rebuilt after every call
+        that can replace tensor objects."""
+        if self._flat is None:
+            self._flat = list(self.state_dict(keep_vars=True).values())
         p = self.pretrained.cls_token
-        return (p.device, self.head_dtype, tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values()))
+        return (p.device, self.head_dtype, tuple((t.data_ptr(), t._version) for t in self._flat))
 
     def _ensure_engine(self):
         dev = self.pretrained.cls_token.device
@@ -109,6 +130,7 @@ class VideoDepthAnything(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("forward() needs a device tensor: the MI355X build has no CPU path")
         eng = self._ensure_engine()
+        eng.encoder_streams = self.encoder_streams
         with torch.cuda.device(x.device):
             return eng.forward(x.float().contiguous())
 
