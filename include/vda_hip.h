@@ -216,6 +216,18 @@ int vda_scale_shift_sums(const float* pred, const float* target, double* sums, l
 int vda_solve_scale_shift(const double* sums, float* ss, void* stream);
 int vda_affine_blend(const float* x, const float* pre, float* out, const float* ss, float w_pre, float w_post, long n, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Metric post-processing (metric_depth/run2.py:42-66, the same code inline at metric_depth/run.py:233-264): rescale every
+ * frame so that the prediction at a reference pixel equals a LiDAR range.
+ * vda_sample_points: out[i] = depth[i][xy[2i+1]][xy[2i]] for fp32 maps [frames][h][w]; the caller has already clamped the
+ *   coordinates into the map (run2.py:51-53).  The handful of scale factors is then computed and interpolated over time
+ *   on the host (run2.py:54-66: N scalars).
+ * vda_scale_frames: out[i][p] = depth[i][p] * scales[i]   (run2.py:67), scales fp32 [frames] in device memory; out may
+ *   alias depth.
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_sample_points(const float* depth, const int* xy, float* out, int frames, int h, int w, void* stream);
+int vda_scale_frames(const float* depth, const float* scales, float* out, int frames, long hw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

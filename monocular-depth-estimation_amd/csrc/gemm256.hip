@@ -42,6 +42,63 @@ __device__ __forceinline__ void phase_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// Epilogue of the fp32 read-modify-write form (out = acc + bias + resid, fp32 in and out; the encoder's proj and fc2 products
+// add into the residual stream this way) for a wave whose 128 x 64 block lies inside the matrix.
+//
+// The general epilogue fetches the residual of one 16-row m-tile, waits, adds, stores, and only then fetches the next: eight
+// exposed memory round trips per wave, with no registers to spare for fetching ahead (the accumulators hold 128).  Here the
+// residual arrives by LDS-DMA instead, which needs no registers: the K loop is over, so each wave owns 16 KiB of the tile
+// buffers as a ring of four 4 KiB slots, keeps the residual of up to four m-tiles in flight, adds its accumulators to a slot
+// in place and copies the slot out in whole 256-byte rows.  A slot is 16 rows x 16 chunks of 16 bytes, lane-linear as the
+// DMA writes it; the chunk stored at position c of row r is column chunk c ^ r (the permutation is applied to the source
+// address, to the fragment accesses and to the store address), which keeps the 16-row fragment accesses conflict-free.
+// Vector-memory operations complete in order, stores included, so the wait before m-tile i counts what was issued after
+// its DMA: with D = the 4 DMA pieces and S = the 4 stores of an m-tile the issue order is D0 D1 D2 D3 S0 D4 S1 D5 S2 D6 S3
+// D7 S4 S5 S6 S7.  Every store below is issued by every wave (no bounds test), or those counts would not hold.
+__device__ __forceinline__ void epilogue_res32_dma(const VdaGemmArgs& p, f32x4 (&acc)[8][4], int m_wave0, int n_wave0, char* slots) {
+    const int lane = threadIdx.x & 63, frow = lane & 15, fq = lane >> 4;
+    const int c = lane & 15, rr = lane >> 4;
+    const float* resid = reinterpret_cast<const float*>(p.resid);
+    float* out = reinterpret_cast<float*>(p.out);
+    f32x4 bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        bias[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n_wave0 + j * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    auto issue = [&](int i) {
+        char* slot = slots + (i & 3) * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = q * 4 + rr;
+            glds16(resid + (size_t)(m_wave0 + i * 16 + r) * p.ldr + n_wave0 + ((c ^ r) << 2), slot + q * 1024);
+        }
+    };
+    auto tile = [&](int i) {
+        char* slot = slots + (i & 3) * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4* ptr = reinterpret_cast<f32x4*>(slot + frow * 256 + (((j * 4 + fq) ^ frow) << 4));
+            *ptr = *ptr + (acc[i][j] + bias[j]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's LDS writes are done before other lanes read them
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = q * 4 + rr;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(slot + r * 256 + (c << 4));
+            *reinterpret_cast<u32x4*>(out + (size_t)(m_wave0 + i * 16 + r) * p.ldc + n_wave0 + ((c ^ r) << 2)) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot has been read before a DMA refills it
+    };
+    issue(0); issue(1); issue(2); issue(3);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); tile(0); issue(4);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); tile(1); issue(5);
+    asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); tile(2); issue(6);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); tile(3); issue(7);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); tile(4);
+    asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); tile(5);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); tile(6);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); tile(7);
+}
+
 // SPEC: the epilogue specialisation (EPI_SPEC_*, gemm_common.h)
 template <int AMODE, bool RELU_IN, int SPEC, typename T>
 __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const GemmTiles gt) {
@@ -208,7 +265,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const
     }
     if (!group1) phase_barrier();     // every wave executes the same number of barriers
 
-    gemm_epilogue_spec<SPEC, T, 8, 4>(p, acc, m0 + wm * 128 + frow, n0 + wn * 64 + fq * 4, fq, smem + wave * STAGE_BYTES);
+    if (SPEC == EPI_SPEC_F32_RES32) {
+        // whole 128 x 64 wave blocks of 16-byte aligned rows take the DMA-fed epilogue (wave-uniform choice)
+        const int m_wave0 = m0 + wm * 128, n_wave0 = n0 + wn * 64;
+        const bool aligned = ((p.ldr | p.ldc) & 3) == 0 && (((uintptr_t)p.resid | (uintptr_t)p.out) & 15) == 0;
+        if (__builtin_amdgcn_readfirstlane(m_wave0 + 128 <= p.M && n_wave0 + 64 <= p.N && aligned)) {
+            scale_acc<8, 4>(p, acc);
+            epilogue_res32_dma(p, acc, m_wave0, n_wave0, smem + wave * 16384);
+            return;
+        }
+    }
+    // (the staging area of a wave lies inside its own 16 KiB, so waves of one workgroup may take different epilogues)
+    static_assert(STAGE_BYTES <= 16384, "a wave's staging area must fit its 16 KiB share of the tile buffers");
+    gemm_epilogue_spec<SPEC, T, 8, 4>(p, acc, m0 + wm * 128 + frow, n0 + wn * 64 + fq * 4, fq, smem + wave * 16384);
 }
 
 template <typename T>

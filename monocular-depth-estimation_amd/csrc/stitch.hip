@@ -72,6 +72,29 @@ __global__ __launch_bounds__(256) void affine_blend_kernel(const float* __restri
     }
 }
 
+// Metric post-processing: one depth value per frame at that frame's reference pixel, and a per-frame scale.
+__global__ void sample_points_kernel(const float* __restrict__ depth, const int* __restrict__ xy, float* __restrict__ out, int n,
+                                     long hw, int w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = depth[(size_t)i * hw + (size_t)xy[2 * i + 1] * w + xy[2 * i]];
+}
+
+// grid (frames, slices): 16 bytes per lane; hw % 4 == 0 is not required (scalar tail)
+__global__ __launch_bounds__(256) void scale_frames_kernel(const float* __restrict__ depth, const float* __restrict__ scales,
+                                                           float* __restrict__ out, long hw) {
+    const float s = scales[blockIdx.x];
+    const float* src = depth + (size_t)blockIdx.x * hw;
+    float* dst = out + (size_t)blockIdx.x * hw;
+    const bool vec = (hw & 3) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+    const long stride = (long)gridDim.y * blockDim.x;
+    if (vec) {
+        for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < hw / 4; i += stride)
+            reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i] * s;
+    } else {
+        for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < hw; i += stride) dst[i] = src[i] * s;
+    }
+}
+
 inline int grid_for(long n) {
     long g = (n + 255) / 256;
     if (g > 2048) g = 2048;
@@ -105,4 +128,21 @@ extern "C" int vda_affine_blend(const float* x, const float* pre, float* out, co
     return hip_rc(hipGetLastError());
 }
 
-extern "C" const char* vda_version(void) { return "vda_hip 0.1 gfx950"; }
+extern "C" int vda_sample_points(const float* depth, const int* xy, float* out, int frames, int h, int w, void* stream) {
+    if (!depth || !xy || !out || frames <= 0 || h <= 0 || w <= 0) return VDA_EINVAL;
+    hipLaunchKernelGGL(sample_points_kernel, dim3((frames + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), depth,
+                       xy, out, frames, (long)h * w, w);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_scale_frames(const float* depth, const float* scales, float* out, int frames, long hw, void* stream) {
+    if (!depth || !scales || !out || frames <= 0 || hw <= 0) return VDA_EINVAL;
+    long slices = (hw / 4 + 255) / 256;
+    if (slices > 64) slices = 64;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(scale_frames_kernel, dim3(frames, (unsigned)slices), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       depth, scales, out, hw);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" const char* vda_version(void) { return "vda_hip 0.2 gfx950"; }

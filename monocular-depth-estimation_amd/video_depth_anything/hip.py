@@ -22,7 +22,7 @@ LSQ_SUMS_DOUBLES = 5 + 4 * 256   # VDA_LSQ_SUMS_DOUBLES: five totals + per-workg
 EXPORTS = [
     "vda_version", "vda_gemm", "vda_gemm_kernel_choice", "vda_attention", "vda_layernorm", "vda_groupnorm", "vda_groupnorm_static", "vda_bilinear_nhwc", "vda_bilinear_f32",
     "vda_im2col_patch14", "vda_assemble_tokens", "vda_temporal_attention", "vda_scale_shift_sums", "vda_solve_scale_shift",
-    "vda_affine_blend", "vda_preprocess_u8", "vda_split3",
+    "vda_affine_blend", "vda_preprocess_u8", "vda_split3", "vda_sample_points", "vda_scale_frames",
 ]
 
 
@@ -74,6 +74,8 @@ def lib():
         l.vda_affine_blend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_long,
                                        C.c_void_p]
         l.vda_preprocess_u8.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+        l.vda_sample_points.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.vda_scale_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p]
         for name in EXPORTS[1:]:
             getattr(l, name).restype = C.c_int
         _lib = l
@@ -297,3 +299,16 @@ def affine_blend(x, pre, out, ss, w_pre, w_post, n):
 def preprocess_u8(frames_u8, out, frames, h0, w0, H, W):
     _dev(frames_u8, out)
     _check(lib().vda_preprocess_u8(_ptr(frames_u8), _ptr(out), frames, h0, w0, H, W, _stream()), "vda_preprocess_u8")
+
+
+def sample_points(depth, xy, out, frames, h, w):
+    """out[i] = depth[i, xy[i, 1], xy[i, 0]]; xy int32 [frames, 2] (x, y) on the device, already inside the map."""
+    _dev(depth, xy, out)
+    if xy.dtype != torch.int32 or depth.dtype != torch.float32:
+        raise TypeError("vda_sample_points: fp32 maps and int32 coordinates")
+    _check(lib().vda_sample_points(_ptr(depth), _ptr(xy), _ptr(out), frames, h, w, _stream()), "vda_sample_points")
+
+
+def scale_frames(depth, scales, out, frames, hw):
+    _dev(depth, scales, out)
+    _check(lib().vda_scale_frames(_ptr(depth), _ptr(scales), _ptr(out), frames, hw, _stream()), "vda_scale_frames")

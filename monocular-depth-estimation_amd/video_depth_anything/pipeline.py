@@ -129,6 +129,24 @@ class HostSink:
         return self.out
 
 
+class DeviceSink:
+    """The HostSink interface for callers that keep the depth video in HBM (metric post-processing on the device)."""
+
+    def __init__(self, n, h0, w0, device):
+        self.out = torch.zeros((n, h0, w0), dtype=torch.float32, device=device)
+        self.have = np.zeros(n, dtype=bool)
+        self.n = n
+
+    def push(self, start, maps):
+        k = min(len(maps), self.n - start)
+        if k > 0:
+            self.out[start:start + k] = torch.stack(list(maps[:k]), 0)
+            self.have[start:start + k] = True
+
+    def result(self):
+        return self.out
+
+
 def owned_runs(n_frames, n_win, stitched, L):
     """Per window, the (first video frame, first slot, count) of the output frames it finalises.  Stitched: window 0 gives
     frames 0..23, window w slots 2..23 -> frames 22w+2.., the last window also its slots 24..31 (video_depth.py:176-205);
@@ -147,7 +165,9 @@ def owned_runs(n_frames, n_win, stitched, L):
     return runs
 
 
-def run_video(model, frames, target_fps, input_size=518, device="cuda", batch_size=16, forward_fn=None, shard_output=None):
+def run_video(model, frames, target_fps, input_size=518, device="cuda", batch_size=16, forward_fn=None, shard_output=None,
+              keep_on_device=False):
+    """``infer_video_depth``.  ``keep_on_device``: return the depth video as a device tensor instead of a numpy array."""
     n = len(frames)
     if n == 0:
         raise ValueError("no frames")
@@ -160,11 +180,11 @@ def run_video(model, frames, target_fps, input_size=518, device="cuda", batch_si
     dev = device
     if dev.type == "cuda":          # every launch below takes the current stream of the CURRENT device: make it `dev`
         with torch.cuda.device(dev):
-            return _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_fn, shard_output, n, h0, w0)
-    return _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_fn, shard_output, n, h0, w0)
+            return _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_fn, shard_output, n, h0, w0, keep_on_device)
+    return _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_fn, shard_output, n, h0, w0, keep_on_device)
 
 
-def _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_fn, shard_output, n, h0, w0):
+def _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_fn, shard_output, n, h0, w0, keep_on_device):
     clamp = bool(getattr(model, "clamp_input_size_on_gpu", False)) and dev.type == "cuda"
     H, W = network_size(h0, w0, input_size, clamp_420=clamp)
     fwd = forward_fn or model.forward
@@ -178,7 +198,9 @@ def _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_f
     src = FrameSource(frames, H, W, dev)
     stitched = L == INFER_LEN and batch_size >= INFER_LEN
     runs = owned_runs(n, n_win, stitched, L)
-    sink = HostSink(n, h0, w0, dev)
+    if keep_on_device and world > 1 and shard_output != "local":
+        raise ValueError("keep_on_device with several ranks needs shard_output='local' (a rank keeps its own frames)")
+    sink = DeviceSink(n, h0, w0, dev) if keep_on_device else HostSink(n, h0, w0, dev)
     stats = dict(world=world, windows=n_win, rounds=-(-n_win // world), gathered_bytes_per_round=0)
 
     def raw_window(w):
@@ -262,7 +284,7 @@ def _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_f
     if model is not None:
         model.last_owned_frames = owner == rank
         model.last_shard_stats = stats
-    if world > 1 and shard_output == "replicate":
+    if world > 1 and shard_output == "replicate" and not keep_on_device:
         _replicate(out, owner, world, rank, dev)
     return out, target_fps
 

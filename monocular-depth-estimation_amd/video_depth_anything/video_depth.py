@@ -144,12 +144,26 @@ class VideoDepthAnything(nn.Module):
         with ``batch_size >= 32`` consecutive windows are affinely aligned and cross-faded, otherwise they are
         concatenated unaligned exactly like the reference does.  ``fp32=True`` runs the windows in the fp32 storage mode
         (see ``precision``); ``use_cpu_offload`` is accepted for signature compatibility (weights stay in HBM).
+
+        Unlike the reference's relative-depth copy, ``device='cuda'`` does NOT clamp ``input_size`` to 420 (video_depth.py:75-78;
+        the reference's CPU path and its metric copy do not clamp either): set ``clamp_input_size_on_gpu = True`` for that.
+        With ``torch.distributed`` initialised the windows are dealt over the ranks (see ``shard_output``).
         """
+        return self._infer_video(frames, target_fps, input_size, device, fp32, batch_size, False)
+
+    @torch.no_grad()
+    def infer_video_depth_device(self, frames, target_fps, input_size=518, device="cuda", fp32=False, batch_size=16):
+        """``infer_video_depth`` that leaves the result in HBM: returns ``(fp32 device tensor [N, H0, W0], target_fps)``,
+        for post-processing on the device (``metric_post.apply_lidar_scaling``).  No counterpart in the reference."""
+        return self._infer_video(frames, target_fps, input_size, device, fp32, batch_size, True)
+
+    def _infer_video(self, frames, target_fps, input_size, device, fp32, batch_size, keep_on_device):
         from .pipeline import run_video
         saved = self.precision
         if fp32:
             self.precision = "fp32"
         try:
-            return run_video(self, frames, target_fps, input_size=input_size, device=device, batch_size=batch_size)
+            return run_video(self, frames, target_fps, input_size=input_size, device=device, batch_size=batch_size,
+                             keep_on_device=keep_on_device)
         finally:
             self.precision = saved

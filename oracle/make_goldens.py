@@ -9,7 +9,7 @@ Weights come from the build's seeded generator (spec.synth_state_dict) and are l
 ``load_state_dict(strict=True)``; only inputs' seeds and the reference's outputs are stored.  While generating,
 the oracle restatement is checked against every reference output (fp32 vs fp32).
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py [--only-clamped]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py [--only-clamped | --only-lidar]
 """
 import json
 import os
@@ -123,6 +123,38 @@ def clamped_profile_goldens(RefVDA):
         np.savez_compressed(os.path.join(GOLD, "g5b_video_clamped.npz"), **g5)
 
 
+def lidar_cases():
+    """Depth videos and LiDAR reference tables for the metric post-processing goldens (G8), seeded."""
+    rs = np.random.RandomState(81)
+    cases = {}
+    n, h, w = 40, 12, 16
+    depths = (rs.rand(n, h, w).astype(np.float32) * 20 + 0.5)
+    depths[7, 5, 9] = 0.0                                     # a reference pixel whose prediction is not positive
+    cases["global"] = (depths, {"global": (None, None, 12.5)})
+    cases["sparse"] = (depths, {3: (9, 5, 8.0), 7: (9, 5, 30.0), 20: (100, 100, 15.0), 33: (0, 11, 4.25)})   # one out of bounds
+    cases["single"] = (depths, {12: (4, 4, 7.0)})
+    cases["none"] = (depths, {})
+    cases["mixed"] = (depths, {"global": (2, 3, 10.0), 5: (15, 11, 40.0), 6: (1, 1, 2.0)})
+    return cases
+
+
+def lidar_goldens():
+    """G8: ``apply_scaling_and_refinement(..., temporal_refine=False)`` of the reference's metric driver
+    (metric_depth/run2.py:42-72), imported from its script with the usual stand-ins."""
+    sys.path.insert(0, "/root/reference/metric_depth")
+    for name in ("imageio", "matplotlib", "matplotlib.cm"):       # imported by the driver's video helpers, unused here
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import run2
+    g8 = {}
+    for name, (depths, refs) in lidar_cases().items():
+        scaled, refined = run2.apply_scaling_and_refinement(list(depths), None, refs, False)
+        mine, factors = O.apply_lidar_scaling(list(depths), refs)
+        check(f"G8 lidar {name}", np.stack(mine), np.stack(scaled), 1e-7)
+        g8[name] = np.stack(scaled).astype(np.float32)
+        g8[name + "_factors"] = np.asarray(factors, np.float64)
+    np.savez_compressed(os.path.join(GOLD, "g8_lidar.npz"), **g8)
+
+
 def main():
     os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
     sys.dont_write_bytecode = True
@@ -131,6 +163,9 @@ def main():
     from video_depth_anything.video_depth import VideoDepthAnything as RefVDA
     if "--only-clamped" in sys.argv:      # add the G4b / G5b fixtures without rewriting the others
         clamped_profile_goldens(RefVDA)
+        return
+    if "--only-lidar" in sys.argv:
+        lidar_goldens()
         return
     from video_depth_anything.util.transform import Resize
     from video_depth_anything.dinov2_layers.block import Block as RefBlock
@@ -286,6 +321,7 @@ def main():
         g7["fusion"] = out
         np.savez_compressed(os.path.join(GOLD, "g7_vitl_width.npz"), **g7)
     clamped_profile_goldens(RefVDA)
+    lidar_goldens()
     print("goldens written to", GOLD)
     for f in sorted(os.listdir(GOLD)):
         print(f"  {f:28s} {os.path.getsize(os.path.join(GOLD, f)) / 1024:.0f} KiB")

@@ -407,6 +407,37 @@ def infer_video_depth(sd, frames, encoder, batch_size=32, forward_fn=None, input
 
 
 # ----------------------------------------------------------------------------------------------------------
+# metric post-processing
+# ----------------------------------------------------------------------------------------------------------
+def apply_lidar_scaling(depths, lidar_refs):
+    """LiDAR reference rescaling of a list / array of depth maps (reference: metric_depth/run2.py:42-67, identical inline at
+    metric_depth/run.py:233-264).  Returns (list of scaled maps, scale factors)."""
+    from scipy.interpolate import interp1d
+    scale_factors = np.ones(len(depths))
+    for i, depth in enumerate(depths):
+        ref = lidar_refs.get(i, lidar_refs.get("global", None))
+        if ref:
+            x, y, lidar_depth = ref
+            if x is None or y is None:
+                h, w = depth.shape
+                x, y = w // 2, h // 2
+            x = min(int(x), depth.shape[1] - 1)
+            y = min(int(y), depth.shape[0] - 1)
+            pred = depth[y, x]
+            if pred > 0:
+                scale_factors[i] = lidar_depth / pred
+    valid = np.where(scale_factors != 1.0)[0]
+    if len(valid) >= 2:
+        f = interp1d(valid, scale_factors[valid], kind="linear", fill_value="extrapolate")
+        for i in range(len(scale_factors)):
+            if scale_factors[i] == 1.0:
+                scale_factors[i] = f(i)
+    elif len(valid) == 1:
+        scale_factors = np.ones(len(depths)) * scale_factors[valid[0]]
+    return [d * scale_factors[i] for i, d in enumerate(depths)], scale_factors
+
+
+# ----------------------------------------------------------------------------------------------------------
 # error metrics
 # ----------------------------------------------------------------------------------------------------------
 def max_rel_err(a, b):

@@ -456,3 +456,27 @@ def test_infer_video_depth_on_a_device_that_is_not_current(vits):
     finally:
         model.to("cuda:0")
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+
+
+def test_lidar_rescaling_on_device_matches_reference_goldens(golden_dir):
+    """metric_depth/run2.py:42-67 on device-resident maps (two launches + N host scalars) and through the numpy entry."""
+    from test_oracle_golden import lidar_cases
+    from video_depth_anything import metric_post as MP
+    g = np.load(os.path.join(golden_dir, "g8_lidar.npz"))
+    for name, (depths, refs) in lidar_cases().items():
+        dev = torch.from_numpy(depths.copy()).cuda()
+        out, factors = MP.apply_lidar_scaling(dev, refs)
+        assert out.data_ptr() == dev.data_ptr()                                   # in place
+        assert np.abs(factors - g[name + "_factors"]).max() <= 1e-6 * np.abs(g[name + "_factors"]).max()
+        assert np.abs(out.cpu().numpy() - g[name]).max() <= 2e-7 * np.abs(g[name]).max(), name
+        host, _ = MP.apply_lidar_scaling(depths, refs)
+        assert host.dtype == np.float32 and np.abs(host - g[name]).max() <= 2e-7 * np.abs(g[name]).max()
+
+
+def test_infer_video_depth_device_keeps_the_result_in_hbm(vits):
+    model, _ = vits
+    frames = synth_frames(40, 28, 42, 11)
+    want, _ = model.infer_video_depth(frames, 30, input_size=28, device="cuda", batch_size=32)
+    got, fps = model.infer_video_depth_device(frames, 30, input_size=28, device="cuda", batch_size=32)
+    assert fps == 30 and got.is_cuda and got.dtype == torch.float32 and tuple(got.shape) == want.shape
+    assert np.array_equal(got.cpu().numpy(), want)

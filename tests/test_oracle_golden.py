@@ -147,3 +147,30 @@ def test_clamped_profile_forward_and_video(golden_dir):
         frames = np.random.RandomState(700 + n).randint(0, 256, (n, 28, 42, 3)).astype(np.uint8)
         out = O.infer_video_depth(sdc, list(frames), "vits", batch_size=bs)
         assert rel(out, g[f"N{n}_bs{bs}"]) < TOL and np.mean(out == 0) >= 0.1
+
+
+def lidar_cases():
+    rs = np.random.RandomState(81)
+    n, h, w = 40, 12, 16
+    depths = (rs.rand(n, h, w).astype(np.float32) * 20 + 0.5)
+    depths[7, 5, 9] = 0.0
+    return {"global": (depths, {"global": (None, None, 12.5)}),
+            "sparse": (depths, {3: (9, 5, 8.0), 7: (9, 5, 30.0), 20: (100, 100, 15.0), 33: (0, 11, 4.25)}),
+            "single": (depths, {12: (4, 4, 7.0)}), "none": (depths, {}),
+            "mixed": (depths, {"global": (2, 3, 10.0), 5: (15, 11, 40.0), 6: (1, 1, 2.0)})}
+
+
+def test_lidar_rescaling_oracle_and_host_logic(golden_dir):
+    """Metric post-processing (metric_depth/run2.py:42-67): the oracle against the reference's outputs, and the package's own
+    host arithmetic (reference pixels, scale factors, temporal propagation without scipy) against the oracle."""
+    from video_depth_anything import metric_post as MP
+    g = np.load(os.path.join(golden_dir, "g8_lidar.npz"))
+    for name, (depths, refs) in lidar_cases().items():
+        scaled, factors = O.apply_lidar_scaling(list(depths), refs)
+        assert rel(np.stack(scaled), g[name]) < 1e-7
+        assert np.array_equal(np.asarray(factors), g[name + "_factors"])
+        n, h, w = depths.shape
+        pix = MP.reference_pixels(refs, n, h, w)
+        pred = np.array([depths[i, r[1], r[0]] if r else 0.0 for i, r in enumerate(pix)], dtype=np.float64)
+        mine = MP._scale_factors(pred, pix)
+        assert np.abs(mine - g[name + "_factors"]).max() <= 1e-12 * np.abs(g[name + "_factors"]).max()

@@ -1,19 +1,31 @@
-"""One shape of vda_attention in a loop (for counter passes): python tools/attn_only.py [frames heads n_tok iters]"""
-import os, sys, torch
+"""Time vda_attention alone on the flagship shape (32 frames x 16 heads x 1370 tokens) or the shape given:
+    python tools/attn_only.py [frames heads tokens] ; VDA_HIP_LIB selects a library build.  Several libraries, interleaved:
+    python tools/attn_only.py --libs a.so b.so  (spawns one process per library and round)"""
+import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if "--libs" in sys.argv:
+    libs = sys.argv[sys.argv.index("--libs") + 1:]
+    for rnd in range(2):
+        for l in libs:
+            out = subprocess.run([sys.executable, __file__], env=dict(os.environ, VDA_HIP_LIB=os.path.abspath(l)), capture_output=True, text=True)
+            print(l, "round", rnd, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:])
+    sys.exit(0)
+import torch
 sys.path.insert(0, os.path.join(ROOT, "monocular-depth-estimation_amd"))
 from video_depth_anything import hip
-frames, heads, n_tok, iters = (int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (32, 16, 1370, 10)))
+a = [int(v) for v in sys.argv[1:4]] if len(sys.argv) >= 4 else [32, 16, 1370]
+frames, heads, n = a
 D = heads * 64
-qkv = torch.randn(frames, n_tok, 3 * D, device="cuda")
-qkv[..., :D] *= 0.125          # the model folds the 1/8 score scale into q
-qkv = qkv.bfloat16()
-out = torch.empty(frames, n_tok, D, device="cuda", dtype=torch.bfloat16)
-for _ in range(3): hip.attention(qkv, out, frames, n_tok, heads)
+g = torch.Generator().manual_seed(0)
+qkv = torch.randn((frames, n, 3 * D), generator=g)
+qkv[..., :D] *= 0.35
+qkv = qkv.bfloat16().cuda()
+out = torch.empty((frames, n, D), dtype=torch.bfloat16, device="cuda")
+for _ in range(5): hip.attention(qkv, out, frames, n, heads)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(iters): hip.attention(qkv, out, frames, n_tok, heads)
+for _ in range(40): hip.attention(qkv, out, frames, n, heads)
 e1.record(); torch.cuda.synchronize()
-t = e0.elapsed_time(e1) / iters
-print(f"attention {frames}x{heads}x{n_tok}: {t*1e3:.1f} us  {4.0*frames*heads*n_tok*n_tok*64/t/1e9:.1f} TF/s")
+us = e0.elapsed_time(e1) / 40 * 1e3
+print(f"attention {frames}x{heads}x{n}: {us:.1f} us  {4.0 * frames * heads * n * n * 64 / us / 1e6:.0f} TFLOP/s")
