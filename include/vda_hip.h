@@ -228,6 +228,18 @@ int vda_affine_blend(const float* x, const float* pre, float* out, const float* 
 int vda_sample_points(const float* depth, const int* xy, float* out, int frames, int h, int w, void* stream);
 int vda_scale_frames(const float* depth, const float* scales, float* out, int frames, long hw, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Depth visualisation, the arithmetic of save_video(..., is_depths=True) (utils/dc_utils.py:72-82): the video's global
+ * minimum and maximum, then per pixel  g = (uint8)((d - min) / (max - min) * 255)  in float32 and a colour table lookup.
+ * vda_minmax_f32: minmax[0..1] = {min, max} of n fp32 values; `minmax` holds VDA_MINMAX_FLOATS floats (the two results
+ *   followed by per-workgroup scratch).
+ * vda_colorize_u8: out[3i..3i+2] = lut[3g..3g+2] (lut: 256 RGB byte triples in device memory, e.g. matplotlib's inferno
+ *   table times 255, truncated) or, with lut == NULL, out[i] = g (the grayscale option).
+ * ------------------------------------------------------------------------------------------------------------- */
+#define VDA_MINMAX_FLOATS (2 + 2 * VDA_LSQ_BLOCKS)
+int vda_minmax_f32(const float* x, float* minmax, long n, void* stream);
+int vda_colorize_u8(const float* depth, const float* minmax, const uint8_t* lut, uint8_t* out, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

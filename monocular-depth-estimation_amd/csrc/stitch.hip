@@ -95,6 +95,52 @@ __global__ __launch_bounds__(256) void scale_frames_kernel(const float* __restri
     }
 }
 
+// Depth visualisation: global minimum / maximum (two passes, fixed grid; min and max do not depend on the order), then
+// 8-bit quantisation with the reference's float32 arithmetic and a colour table lookup.
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long n) {
+    __shared__ float red[2][4];
+    float lo = INFINITY, hi = -INFINITY;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = lo; red[1][wave] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+        part[2 * blockIdx.x + 1] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    }
+}
+
+__global__ void minmax_final_kernel(float* __restrict__ mm, const float* __restrict__ part) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int b = threadIdx.x; b < LSQ_BLOCKS; b += 64) { lo = fminf(lo, part[2 * b]); hi = fmaxf(hi, part[2 * b + 1]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    if (threadIdx.x == 0) { mm[0] = lo; mm[1] = hi; }
+}
+
+// one pixel per thread: index = (uint8)((d - lo) / (hi - lo) * 255), each step rounded to float32 like numpy's
+__global__ __launch_bounds__(256) void colorize_kernel(const float* __restrict__ depth, const float* __restrict__ mm,
+                                                       const unsigned char* __restrict__ lut, unsigned char* __restrict__ out, long n) {
+    const float lo = mm[0], range = mm[1] - mm[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float t = __fmul_rn(__fdiv_rn(__fsub_rn(depth[i], lo), range), 255.0f);
+        const int g = (int)t & 255;             // numpy's float -> uint8 cast truncates; the value is within 0..255
+        if (lut) {
+            out[3 * i] = lut[3 * g];
+            out[3 * i + 1] = lut[3 * g + 1];
+            out[3 * i + 2] = lut[3 * g + 2];
+        } else {
+            out[i] = (unsigned char)g;
+        }
+    }
+}
+
 inline int grid_for(long n) {
     long g = (n + 255) / 256;
     if (g > 2048) g = 2048;
@@ -142,6 +188,21 @@ extern "C" int vda_scale_frames(const float* depth, const float* scales, float* 
     if (slices < 1) slices = 1;
     hipLaunchKernelGGL(scale_frames_kernel, dim3(frames, (unsigned)slices), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        depth, scales, out, hw);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_minmax_f32(const float* x, float* minmax, long n, void* stream) {
+    if (!x || !minmax || n <= 0) return VDA_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(LSQ_BLOCKS), dim3(256), 0, s, x, minmax + 2, n);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, s, minmax, minmax + 2);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_colorize_u8(const float* depth, const float* minmax, const uint8_t* lut, uint8_t* out, long n, void* stream) {
+    if (!depth || !minmax || !out || n <= 0) return VDA_EINVAL;
+    hipLaunchKernelGGL(colorize_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), depth, minmax, lut,
+                       out, n);
     return hip_rc(hipGetLastError());
 }
 

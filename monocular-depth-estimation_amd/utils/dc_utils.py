@@ -35,19 +35,16 @@ def read_video_frames(video_path, process_length=-1, target_fps=-1, max_res=-1):
 
 
 def save_video(frames, output_video_path, fps=10, is_depths=False, grayscale=False):
-    """Write frames (or depth maps normalised to 8 bits) with imageio's ffmpeg writer."""
+    """Write frames, or depth maps normalised to 8 bits and coloured with the inferno table, with imageio's ffmpeg writer
+    (reference: utils/dc_utils.py:72-86)."""
     try:
         import imageio
     except ImportError as e:
         raise ImportError("save_video needs imageio with the ffmpeg plugin") from e
     writer = imageio.get_writer(output_video_path, fps=fps, macro_block_size=1, codec="libx264", ffmpeg_params=["-crf", "18"])
-    if is_depths:
-        lo, hi = float(np.min(frames)), float(np.max(frames))
-        for d in frames:
-            g = ((d - lo) / max(hi - lo, 1e-12) * 255).astype(np.uint8)
-            if not grayscale:
-                import matplotlib.cm as cm
-                g = (cm.get_cmap("inferno")(g)[..., :3] * 255).astype(np.uint8)
+    if is_depths:       # normalisation and colour table on the device (video_depth_anything/visualize.py)
+        from video_depth_anything.visualize import colorize_depth
+        for g in colorize_depth(frames, grayscale=grayscale):
             writer.append_data(g)
     else:
         for f in frames:

@@ -22,7 +22,7 @@ LSQ_SUMS_DOUBLES = 5 + 4 * 256   # VDA_LSQ_SUMS_DOUBLES: five totals + per-workg
 EXPORTS = [
     "vda_version", "vda_gemm", "vda_gemm_kernel_choice", "vda_attention", "vda_layernorm", "vda_groupnorm", "vda_groupnorm_static", "vda_bilinear_nhwc", "vda_bilinear_f32",
     "vda_im2col_patch14", "vda_assemble_tokens", "vda_temporal_attention", "vda_scale_shift_sums", "vda_solve_scale_shift",
-    "vda_affine_blend", "vda_preprocess_u8", "vda_split3", "vda_sample_points", "vda_scale_frames",
+    "vda_affine_blend", "vda_preprocess_u8", "vda_split3", "vda_sample_points", "vda_scale_frames", "vda_minmax_f32", "vda_colorize_u8",
 ]
 
 
@@ -76,6 +76,8 @@ def lib():
         l.vda_preprocess_u8.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
         l.vda_sample_points.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.vda_scale_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p]
+        l.vda_minmax_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+        l.vda_colorize_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         for name in EXPORTS[1:]:
             getattr(l, name).restype = C.c_int
         _lib = l
@@ -312,3 +314,16 @@ def sample_points(depth, xy, out, frames, h, w):
 def scale_frames(depth, scales, out, frames, hw):
     _dev(depth, scales, out)
     _check(lib().vda_scale_frames(_ptr(depth), _ptr(scales), _ptr(out), frames, hw, _stream()), "vda_scale_frames")
+
+
+MINMAX_FLOATS = 2 + 2 * 256        # VDA_MINMAX_FLOATS
+
+
+def minmax_f32(x, minmax, n):
+    _dev(x, minmax)
+    _check(lib().vda_minmax_f32(_ptr(x), _ptr(minmax), n, _stream()), "vda_minmax_f32")
+
+
+def colorize_u8(depth, minmax, lut, out, n):
+    _dev(depth, minmax, lut, out)
+    _check(lib().vda_colorize_u8(_ptr(depth), _ptr(minmax), _ptr(lut), _ptr(out), n, _stream()), "vda_colorize_u8")

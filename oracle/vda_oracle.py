@@ -437,6 +437,18 @@ def apply_lidar_scaling(depths, lidar_refs):
     return [d * scale_factors[i] for i, d in enumerate(depths)], scale_factors
 
 
+def colorize_depth(frames, table_u8=None):
+    """8-bit visualisation of a depth video (reference: utils/dc_utils.py:75-81): ``table_u8`` = 256 RGB byte triples
+    (inferno) or None for grayscale."""
+    frames = np.asarray(frames)
+    d_min, d_max = frames.min(), frames.max()
+    out = []
+    for i in range(frames.shape[0]):
+        g = ((frames[i] - d_min) / (d_max - d_min) * 255).astype(np.uint8)
+        out.append(table_u8[g] if table_u8 is not None else g)
+    return np.stack(out)
+
+
 # ----------------------------------------------------------------------------------------------------------
 # error metrics
 # ----------------------------------------------------------------------------------------------------------

@@ -480,3 +480,15 @@ def test_infer_video_depth_device_keeps_the_result_in_hbm(vits):
     got, fps = model.infer_video_depth_device(frames, 30, input_size=28, device="cuda", batch_size=32)
     assert fps == 30 and got.is_cuda and got.dtype == torch.float32 and tuple(got.shape) == want.shape
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("chunk", [64, 2])
+def test_depth_visualisation_on_device_is_bit_exact(golden_dir, chunk):
+    """save_video's depth colouring (utils/dc_utils.py:72-82) on the device: byte for byte the frames the reference writes."""
+    from video_depth_anything.visualize import colorize_depth
+    g = np.load(os.path.join(golden_dir, "g9_visualisation.npz"))
+    assert np.array_equal(colorize_depth(g["depths"], chunk=chunk), g["inferno"])
+    assert np.array_equal(colorize_depth(torch.from_numpy(g["depths"]).cuda(), grayscale=True, chunk=chunk), g["gray"])
+    big = (np.random.RandomState(3).rand(3, 480, 640).astype(np.float32) ** 3) * 80
+    table = np.load(os.path.join(os.path.dirname(spec.__file__), "inferno_u8.npy"))
+    assert np.array_equal(colorize_depth(big), O.colorize_depth(big, table))

@@ -174,3 +174,11 @@ def test_lidar_rescaling_oracle_and_host_logic(golden_dir):
         pred = np.array([depths[i, r[1], r[0]] if r else 0.0 for i, r in enumerate(pix)], dtype=np.float64)
         mine = MP._scale_factors(pred, pix)
         assert np.abs(mine - g[name + "_factors"]).max() <= 1e-12 * np.abs(g[name + "_factors"]).max()
+
+
+def test_depth_visualisation_oracle_matches_reference_frames(golden_dir):
+    """utils/dc_utils.py:72-82: what the reference hands to its video writer, bit for bit; the package's inferno byte table."""
+    g = np.load(os.path.join(golden_dir, "g9_visualisation.npz"))
+    table = np.load(os.path.join(os.path.dirname(spec.__file__), "inferno_u8.npy"))
+    assert np.array_equal(O.colorize_depth(g["depths"], table), g["inferno"])
+    assert np.array_equal(O.colorize_depth(g["depths"], None), g["gray"])
