@@ -1,9 +1,9 @@
 // Flash-style multi-head self-attention for head dim 64 (see vda_attention in include/vda_hip.h).
 //
 // One workgroup = 4 waves = 128 NQB query rows of one (frame, head); each wave owns NQB blocks of 32 queries (with NQB = 2
-// every K and V fragment read from LDS feeds two MFMAs: half the LDS traffic per MFMA for 244 instead of 148 registers).  K/V tiles of 64 keys are
-// staged through registers into double-buffered LDS (loads of tile t+1 are issued before the math of tile t and
-// written to LDS after it).  Scores are computed TRANSPOSED, S^T = K Q^T with mfma_32x32x16, so that the query index
+// every K and V fragment read from LDS feeds two MFMAs: half the LDS traffic per MFMA for more registers).  K/V tiles of 64
+// keys are copied global -> LDS by global_load_lds into a double buffer (the copy of tile t+1 is in flight during the math
+// of tile t); the fp32 variant stages through registers, where it splits the values.  Scores are computed TRANSPOSED, S^T = K Q^T with mfma_32x32x16, so that the query index
 // lives on the lane: every lane owns one query's running max / sum, the softmax needs one cross-lane exchange
 // (lane ^ 32) per tile, and the fp32 score registers, converted to bf16, are directly the B operand of the second
 // product O^T += V^T P^T (an accumulator tile reused as the next MFMA's operand; its k order is permuted and the V^T
@@ -49,27 +49,22 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
         for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
     }
 
-    // staging: thread copies 2 K pieces and 2 V pieces (16 bytes each) per tile
+    // staging: per tile every thread copies 2 K pieces and 2 V pieces of 16 bytes straight from global memory into LDS
+    // (global_load_lds: no staging registers, no LDS store instructions).  The LDS image is lane-linear, so the bank swizzles
+    // of tile_off() / v_off() are applied to the SOURCE chunk each lane fetches: the lane that fills position sc of a row
+    // fetches chunk sc ^ swizzle(row), which is what those functions' readers expect to find there.
     const int srow = tid >> 3, sc = tid & 7;
-    const bf16* kbase = base + D + sc * 8;
-    const bf16* vbase = base + 2 * D + sc * 8;
-    u32x4 kreg[2], vreg[2];
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const size_t row = (size_t)min(kt * 64 + i * 32 + srow, n_tok - 1) * ld;
-            kreg[i] = *reinterpret_cast<const u32x4*>(kbase + row);
-            vreg[i] = *reinterpret_cast<const u32x4*>(vbase + row);
-        }
-    };
-    auto write_tile = [&](int buf) {
+    const bf16* kbase = base + D;
+    const bf16* vbase = base + 2 * D;
+    auto stage_tile = [&](int kt, int buf) {
         char* kb = smem + buf * 16384;
         char* vb = kb + 8192;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = i * 32 + srow;
-            *reinterpret_cast<u32x4*>(kb + tile_off(row, sc)) = kreg[i];
-            *reinterpret_cast<u32x4*>(vb + v_off(row, sc * 8)) = vreg[i];
+            const size_t g = (size_t)min(kt * 64 + row, n_tok - 1) * ld;
+            glds16(kbase + g + ((sc ^ ((row >> 1) & 7)) << 3), kb + i * 4096 + wave * 1024);
+            glds16(vbase + g + ((sc ^ (((row >> 1) & 1) << 2)) << 3), vb + i * 4096 + wave * 1024);
         }
     };
 
@@ -84,13 +79,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
     }
 
     const int nkt = (n_tok + 63) / 64;
-    load_tile(0);
-    write_tile(0);
+    stage_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler also drains the copies in front of a barrier)
     __syncthreads();
     // The Q fragments come from plain global loads.  Redefine them here, once they have landed: otherwise the compiler carries
     // "these registers may still be in flight" around the loop and waits, before the first products of EVERY tile, with counts
     // that also cover the K/V loads it has just issued for the next tile (vector memory operations complete in order).
-    // Worth 8 % of the kernel.
+    // Worth 3 % of the kernel.
 #pragma unroll
     for (int b = 0; b < NQB; ++b)
 #pragma unroll
@@ -102,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        if (kt + 1 < nkt) stage_tile(kt + 1, cur ^ 1);      // lands while this tile is multiplied; read after the barrier below
         const char* kb = smem + cur * 16384;
         const char* vb = kb + 8192;
 
@@ -177,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
                     for (int b = 0; b < NQB; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][kbk][s2], o[b][db], 0, 0, 0);
                 }
 
-        if (kt + 1 < nkt) write_tile(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's copies of the next tile have landed
         __syncthreads();
     }
 
