@@ -107,11 +107,14 @@ int vda_gemm_kernel_choice(const VdaGemmArgs* args);
 /* ---------------------------------------------------------------------------------------------------------------
  * Multi-head self-attention over the tokens of each frame, head dim 64, no mask, flash-style (scores never leave
  * the CU).  qkv: [frames][n_tok][3*heads*64] laid out [q | k | v] x [head][64] as produced by the fused QKV
- * projection, q already multiplied by 64^-1/2; out: [frames][n_tok][heads*64]; both of type dtype.
+ * projection, q already multiplied by log2(e) * 64^-1/2 (VDA_ATTENTION_Q_SCALE): the scores are then base-2 logarithms
+ * and the probabilities 2^(score - max), which is what the hardware's exponential computes; out:
+ * [frames][n_tok][heads*64]; both of type dtype.
  * dtype VDA_T_BF16: bf16 operands.  dtype VDA_T_F32: fp32 in and out; q, k, v and the probabilities are split into
  * IEEE-half hi/lo pairs on the fly (after scaling by powers of two) and every product is the three-term hi/lo sum.
  * Replaces attention.py:51-59 of the reference (dinov2_layers).
  * ------------------------------------------------------------------------------------------------------------- */
+#define VDA_ATTENTION_Q_SCALE 0.18033688011112042   /* log2(e) / 8 */
 int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -12,16 +12,18 @@
 
 namespace {
 
-constexpr float LOG2E = 1.4426950408889634f;
 
 // byte offset of element (key row, 16-bit column col) in the V tile: 128-byte rows, the two 64-byte halves of a row
 // swapped on rows 2,3 (mod 4) so the 4 rows of a transposed 4x16 block read fall on distinct banks
 __device__ __forceinline__ int v_off(int row, int col) { return row * 128 + ((col * 2) ^ (((row >> 1) & 1) << 6)); }
 
-// Growth of the running maximum (natural-log units) below which the accumulated output is NOT rescaled: probabilities of a
-// tile may then reach e^DEFER instead of 1, harmless for bf16 operands with fp32 accumulation, and the 64-register
-// rescale pass is skipped on almost every tile once the maximum has settled.
-constexpr float DEFER = 4.0f;
+// Scores are base-2 logarithms: the caller folds log2(e) / sqrt(64) into q, so a probability is exp2(score - maximum) and
+// v_exp_f32 needs no multiply in front of it.
+//
+// Growth of the running maximum (in those units) below which the accumulated output is NOT rescaled: probabilities of a tile
+// may then reach 2^DEFER instead of 1, harmless for 16-bit operands with fp32 accumulation, and the rescale pass is skipped on
+// almost every tile once the maximum has settled.
+constexpr float DEFER = 6.0f;
 
 template <int NQB>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int n_tok, int heads, int q_blocks) {
@@ -68,14 +70,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
         }
     };
 
-    f32x16 o[NQB][2];
+    f32x16 o[NQB][2], negm[NQB];
     float m_run[NQB], l_run[NQB];
 #pragma unroll
     for (int b = 0; b < NQB; ++b) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { o[b][0][i] = 0.f; o[b][1][i] = 0.f; }
-        m_run[b] = -INFINITY;
+        m_run[b] = 0.f;
         l_run[b] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[b][i] = 0.f;
     }
 
     const int nkt = (n_tok + 63) / 64;
@@ -101,18 +105,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
         const char* kb = smem + cur * 16384;
         const char* vb = kb + 8192;
 
+        // The products are accumulated onto -m_run (negm: sixteen copies of it, the C operand of the first product of each
+        // chain), so s comes out as score MINUS running maximum and the exponentials below need no subtraction: one VALU
+        // instruction per score less, in a loop whose pace is set by vector instruction issue, not by the matrix pipe.
         f32x16 s[NQB][2];
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk) {
 #pragma unroll
-            for (int b = 0; b < NQB; ++b)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s[b][kbk][i] = 0.f;
-#pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + tile_off(32 * kbk + r, 2 * ks + h));
 #pragma unroll
-                for (int b = 0; b < NQB; ++b) s[b][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][ks], s[b][kbk], 0, 0, 0);
+                for (int b = 0; b < NQB; ++b)
+                    s[b][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][ks], ks == 0 ? negm[b] : s[b][kbk], 0, 0, 0);
             }
         }
         bf16x8 pf[NQB][2][2];
@@ -133,23 +137,27 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
 #pragma unroll
             for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[b][1][i]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            // Everything accumulated so far (o, l_run) is at scale exp(-m_run).  Move to a new maximum only if some query of
-            // the block needs it (wave-uniform branch); all of the previous tile's P V products are already in o.
-            if (__builtin_amdgcn_ballot_w64(mx - m_run[b] > DEFER) != 0) {
-                const float m_new = fmaxf(m_run[b], mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * LOG2E);
-                m_run[b] = m_new;
+            // Everything accumulated so far (o, l_run) is at scale 2^-m_run.  Move to a new maximum only if some query of the
+            // block needs it (wave-uniform branch; always on the first tile, which sets the maximum whatever its sign); this
+            // tile's scores, already relative to the old maximum, move with it.
+            if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > DEFER) != 0) {
+                const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+                const float alpha = kt == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                m_run[b] += delta;
                 l_run[b] *= alpha;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { o[b][0][i] *= alpha; o[b][1][i] *= alpha; }
+                for (int i = 0; i < 16; ++i) {
+                    o[b][0][i] *= alpha; o[b][1][i] *= alpha;
+                    s[b][0][i] -= delta; s[b][1][i] -= delta;
+                    negm[b][i] = -m_run[b];
+                }
             }
-            const float mneg = -m_run[b] * LOG2E;
             float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[b][kbk][i], LOG2E, mneg));
+                    const float pv = __builtin_amdgcn_exp2f(s[b][kbk][i]);
                     ps[i & 3] += pv;
                     pf[b][kbk][i >> 3][i & 7] = (bf16)pv;
                 }
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
 // fp32 storage mode: q, k, v and the output are fp32.  K and V tiles are split into IEEE-half hi/lo images while they are
 // staged (registers -> LDS), q and the probabilities are split in registers, and every product is the three-term sum
 // hi*hi + hi*lo + lo*hi on the fp16 matrix cores with fp32 accumulation.  Values are multiplied by powers of two before
-// the split (q, k, v by QKV_SCALE, probabilities, which reach e^DEFER = 55, by P_SCALE) so that the low halves are normal
+// the split (q, k, v by QKV_SCALE, probabilities, which reach 2^DEFER = 64, by P_SCALE) so that the low halves are normal
 // numbers, and the sums are scaled back.  Same structure as attn_kernel<1> otherwise.
 constexpr float QKV_SCALE = 16.f, P_SCALE = 256.f;
 typedef short i16x4 __attribute__((ext_vector_type(4)));
@@ -319,20 +327,19 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restr
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         if (__builtin_amdgcn_ballot_w64(mx - m_run > DEFER) != 0) {
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
             l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
         }
-        const float mneg = -m_run * LOG2E;
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
         f16x8 ph[2][2], pl[2][2];
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float pv = exp2f(fmaf(s[kbk][i], LOG2E, mneg));       // full-precision exp2 in this mode
+                const float pv = exp2f(s[kbk][i] - m_run);       // full-precision exp2 in this mode
                 ps[i & 3] += pv;
                 f16 x, y;
                 split_f16(pv * P_SCALE, x, y);

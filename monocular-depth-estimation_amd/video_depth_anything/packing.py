@@ -4,11 +4,14 @@ Everything here runs once per (weights, device): it is preparation, not the per-
   * every GEMM weight is bf16 ``[N][K]`` (K contiguous) with K and all channel counts zero-padded to multiples of 64;
   * 3x3 conv weights ``[Cout][Cin][3][3]`` become ``[Cout][tap = ky*3+kx][Cin]``;
   * ConvTranspose weights ``[Cin][Cout][k][k]`` become ``[(ky*k+kx)*Cout + co][Cin]``;
-  * the attention scale 64^-1/2 = 1/8 is folded into the q rows of the fused QKV weight and bias (exact in bf16);
+  * the attention scale 64^-1/2 times log2(e) is folded into the q rows of the fused QKV weight and bias (in fp32, before
+    the one rounding to the operand type): vda_attention works on base-2 scores;
   * the GEGLU projection rows are interleaved value/gate in blocks of 16 (see VDA_EPI_GEGLU);
   * biases, LayerScale, norm parameters and the temporal position tables stay fp32.
 """
 import math
+
+ATTENTION_Q_SCALE = math.log2(math.e) / 8.0      # VDA_ATTENTION_Q_SCALE of the C header
 
 import numpy as np
 import torch
@@ -155,8 +158,8 @@ class PackedWeights:
         for i in range(depth):
             b = f"{p}blocks.{i}."
             wqkv, bqkv = g(b + "attn.qkv.weight").clone(), g(b + "attn.qkv.bias").clone()
-            wqkv[:D] *= 0.125
-            bqkv[:D] *= 0.125
+            wqkv[:D] *= ATTENTION_Q_SCALE
+            bqkv[:D] *= ATTENTION_Q_SCALE
             # LayerScale (layer_scale.py:27-28) is folded into the projection it follows: gamma * (x W^T + b) =
             # x (gamma W)^T + gamma b, rounded to the operand type once, from the fp32 product.  The residual GEMMs then
             # have a plain "+ bias + residual" epilogue.

@@ -298,6 +298,11 @@ def test_fused_bilinear_input_is_refused_where_the_direct_kernel_does_not_apply(
         hip.gemm(x, wg, out, M=100, N=48, K=9 * 64, lda=0, ldc=48, conv=(10, 10, 64, 10, 10, 1), upsample_from=(5, 5))
 
 
+def softmax2(scores):
+    """The kernel's scores are base-2 logarithms (log2(e) is folded into q with the 1/8): probabilities 2^s / sum 2^s."""
+    return torch.softmax(scores * math.log(2.0), -1)
+
+
 @pytest.mark.parametrize("frames,n_tok,heads", [(2, 1370, 6), (3, 64, 2), (1, 129, 16), (2, 36, 1), (1, 4100, 2), (1, 5477, 1)])
 def test_attention(frames, n_tok, heads):
     D = heads * 64
@@ -305,7 +310,7 @@ def test_attention(frames, n_tok, heads):
     out = torch.full((frames, n_tok, D), float("nan"), dtype=BF, device=DEV)
     hip.attention(qkv, out, frames, n_tok, heads)
     q, k, v = qkv.float().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
-    want = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(frames, n_tok, D)
+    want = (softmax2(q @ k.transpose(-1, -2)) @ v).transpose(1, 2).reshape(frames, n_tok, D)
     close(out, want, 1.2e-2, "attention")       # probabilities are rounded to bf16 before the second product
 
 
@@ -319,8 +324,24 @@ def test_attention_sharp_softmax_rescale(n_tok):
     out = torch.empty((frames, n_tok, 64), dtype=BF, device=DEV)
     hip.attention(qkv, out, frames, n_tok, heads)
     q, k, v = qkv.float().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
-    want = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(frames, n_tok, 64)
+    want = (softmax2(q @ k.transpose(-1, -2)) @ v).transpose(1, 2).reshape(frames, n_tok, 64)
     close(out, want, 1.2e-2, "attention rescale")
+
+
+@pytest.mark.parametrize("n_tok", [130, 4200])
+@pytest.mark.parametrize("offset", [-300.0, 300.0])
+def test_attention_scores_far_from_zero(n_tok, offset):
+    """Every score of a query is near `offset`: the first tile must set the running maximum whatever its sign (2^-300 and
+    2^300 are not fp32 numbers), and later tiles stay relative to it."""
+    frames, heads = 1, 1
+    qkv = rnd((frames, n_tok, 192), 5, 0.5)
+    qkv[..., 63] = 16.0                                   # q[63] = 16
+    qkv[..., 127] = offset / 16.0                         # k[63]: adds `offset` to every score (exact in bf16)
+    out = torch.full((frames, n_tok, 64), float("nan"), dtype=BF, device=DEV)
+    hip.attention(qkv, out, frames, n_tok, heads)
+    q, k, v = qkv.double().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    want = (softmax2(q @ k.transpose(-1, -2)) @ v).transpose(1, 2).reshape(frames, n_tok, 64).float()
+    close(out, want, 1.2e-2, "attention, shifted scores")
 
 
 @pytest.mark.parametrize("rows,C", [(1370 * 2, 1024), (100, 384), (37, 64), (50, 192)])
@@ -577,7 +598,7 @@ def test_attention_fp32_mode(frames, n_tok, heads):
     out = torch.full((frames, n_tok, D), float("nan"), dtype=torch.float32, device=DEV)
     hip.attention(qkv, out, frames, n_tok, heads)
     q, k, v = qkv.double().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
-    want = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(frames, n_tok, D).float()
+    want = (softmax2(q @ k.transpose(-1, -2)) @ v).transpose(1, 2).reshape(frames, n_tok, D).float()
     close(out, want, 3e-6, "attention, fp32 mode")
 
 
