@@ -248,17 +248,28 @@ def end_to_end(model, H, W, n=98):
     device preprocessing, all windows, alignment, cross-fade and the copy of every depth map back to the host.  Not part
     of `value`: it is the PCIe-inclusive rate of the whole video path, in VIDEO frames (a window advances 22 frames)."""
     frames = np.random.RandomState(1).randint(0, 256, (n, H, W, 3), dtype=np.uint8)
-    model.infer_video_depth(frames[:33], 30, input_size=min(H, W), device="cuda", batch_size=32)      # warm-up
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    depth, _ = model.infer_video_depth(frames, 30, input_size=min(H, W), device="cuda", batch_size=32)
-    dt = time.perf_counter() - t0
-    assert depth.shape == (n, H, W)
     from video_depth_anything.windows import window_plan
     windows = len(window_plan(n, 32)[0])
-    return {"video_frames_per_s": round(n / dt, 2), "model_frames_per_s": round(32 * windows / dt, 2), "frames": n,
-            "windows": windows, "seconds": round(dt, 3),
-            "path": "host uint8 frames -> infer_video_depth(batch_size=32) -> host fp32 depth (PCIe both ways included)"}
+    model.infer_video_depth(frames[:33], 30, input_size=min(H, W), device="cuda", batch_size=32)      # warm-up
+    res = {}
+    # second leg: every window recomputes the encoder outputs of the ten frames it shares with the window before it, as
+    # the reference does (reuse_encoder_features = False)
+    for name, reuse in (("", True), ("_recomputing_shared_frames", False)):
+        model.reuse_encoder_features = reuse
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        depth, _ = model.infer_video_depth(frames, 30, input_size=min(H, W), device="cuda", batch_size=32)
+        dt = time.perf_counter() - t0
+        assert depth.shape == (n, H, W)
+        res["video_frames_per_s" + name] = round(n / dt, 2)
+        res["seconds" + name] = round(dt, 3)
+    model.reuse_encoder_features = True
+    res.update({"model_frames_per_s_recomputing_shared_frames": round(32 * windows / res["seconds_recomputing_shared_frames"], 2),
+                "frames": n, "windows": windows,
+                "path": "host uint8 frames -> infer_video_depth(batch_size=32) -> host fp32 depth (PCIe both ways included); by "
+                        "default a window takes the encoder outputs of the 10 frames it shares with the window before it from "
+                        "that window"})
+    return res
 
 
 def sharded_video(model, H, W, world, rank, dev, barrier, rounds=4):

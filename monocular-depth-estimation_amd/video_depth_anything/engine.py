@@ -34,6 +34,7 @@ class Engine:
         self.act_scale = ACT_SPLIT_SCALE if SPLIT_DTYPE == torch.float16 else 1.0
         self.encoder_streams = 2      # frame groups of the encoder that run on concurrent streams (see encoder())
         self.side_streams = []
+        self.kept = None              # encoder outputs of the last keyed forward() (see forward)
 
     # ---- small wrappers -------------------------------------------------------------------------------------------
     def operand(self, a, relu=False, act=None):
@@ -99,25 +100,38 @@ class Engine:
         return out
 
     # ---- encoder (reference: dinov2.py:212-231, 271-281, 297-321; block.py:82-107) --------------------------------------
-    def encoder(self, x, frames, H, W):
+    def encoder(self, x, frames, H, W, carried=None):
         """The four tapped, normalised token maps [frames * hw, D].  The encoder treats every frame on its own, so the frames
         are split into ``self.encoder_streams`` groups that run on separate HIP streams: while one group's workgroups drain
         at the end of a kernel (a GEMM grid rarely fills its last round of tiles) or wait on HBM (LayerNorm, residual
-        epilogues), the other group's matrix-bound kernels take the idle CUs.  Same kernels on the same rows: same bits."""
+        epilogues), the other group's matrix-bound kernels take the idle CUs.  Same kernels on the same rows: same bits.
+
+        ``carried = (previous taps, slots)``: the first ``len(slots)`` frames are the frames at ``slots`` of an earlier call
+        whose tap buffers are given; their rows are copied instead of computed (a frame's encoder output does not depend on
+        the other frames of its window, and consecutive windows of a video share ten of 32 frames, video_depth.py:157-164)."""
         w, dev = self.w, self.dev
         hw = (H // 14) * (W // 14)
         taps = [_empty((frames * hw, w.D), self.hdt, dev) for _ in w.taps]
+        first = 0
+        if carried is not None:
+            prev, slots = carried
+            first = len(slots)
+            idx = torch.tensor(slots, dtype=torch.int64, device=dev)
+            for t, p in zip(taps, prev):
+                torch.index_select(p.view(-1, hw * w.D), 0, idx, out=t[:first * hw].view(first, hw * w.D))
+        if first == frames:
+            return taps
         w.pos_table(H // 14, W // 14)             # built (and uploaded) on this stream before any other stream reads it
-        groups = min(self.encoder_streams, frames)
+        groups = min(self.encoder_streams, frames - first)
         if groups <= 1:
-            self.encoder_frames(x, 0, frames, H, W, taps)
+            self.encoder_frames(x, first, frames, H, W, taps)
             return taps
         main = torch.cuda.current_stream()
         if len(self.side_streams) < groups - 1:
             self.side_streams += [torch.cuda.Stream(device=dev) for _ in range(groups - 1 - len(self.side_streams))]
         fork = torch.cuda.Event()
         fork.record(main)
-        bounds = [frames * g // groups for g in range(groups + 1)]
+        bounds = [first + (frames - first) * g // groups for g in range(groups + 1)]
         joins = []
         for g in range(1, groups):
             side = self.side_streams[g - 1]
@@ -255,11 +269,28 @@ class Engine:
                    resized=(14 * hp, 14 * wp))
         return depth
 
-    def forward(self, x):
+    def forward(self, x, frame_keys=None):
         """x: fp32 [B, T, 3, H, W] on the device -> fp32 [B, T, H, W] (reference: video_depth.py:58-65).
         The reference's trailing resize to (H, W) is the identity (the head already emits 14*hp x 14*wp = H x W with
-        align_corners=True) and its ReLU is idempotent after the head's own, so neither is launched."""
+        align_corners=True) and its ReLU is idempotent after the head's own, so neither is launched.
+
+        ``frame_keys`` (B = 1): one hashable identity per frame.  The encoder outputs of this call are kept, and the leading
+        frames whose keys were part of the previous keyed call (at the same size) take their encoder outputs from it."""
         B, T, ch, H, W = x.shape
         hp, wp = H // 14, W // 14
-        taps = self.encoder(x.reshape(B * T, ch, H, W), B * T, H, W)
+        carried = None
+        keyed = frame_keys is not None and B == 1
+        if keyed:
+            if len(frame_keys) != T:
+                raise ValueError(f"frame_keys: {len(frame_keys)} keys for {T} frames")
+            kept = self.kept
+            if kept is not None and kept["size"] == (H, W):
+                n = 0
+                while n < T and frame_keys[n] in kept["slot"]:
+                    n += 1
+                if n:
+                    carried = (kept["taps"], [kept["slot"][k] for k in frame_keys[:n]])
+        taps = self.encoder(x.reshape(B * T, ch, H, W), B * T, H, W, carried)
+        if keyed:
+            self.kept = dict(size=(H, W), slot={k: i for i, k in enumerate(frame_keys)}, taps=taps)
         return self.head(taps, B, T, hp, wp).reshape(B, T, H, W)

@@ -3,6 +3,8 @@
 Differences from the reference's data flow (results are the same function of the frames):
   * frames are uploaded once as uint8 and preprocessed on the device; a frame that appears in several windows is
     preprocessed once and cached, instead of a 103 MB fp32 host->device copy per window;
+  * a window takes the encoder outputs of the frames it shares with the window before it (ten of 32) from that window
+    instead of recomputing them (``model.reuse_encoder_features``);
   * the full-resolution upsample, the least-squares alignment and the cross-fade run on the device; only final maps are
     copied back, from a side stream, into a small ring of pinned buffers, while the next window is computed;
   * with ``torch.distributed`` initialised (one process per GPU, backend "nccl" = RCCL) the windows are dealt round-robin:
@@ -187,7 +189,12 @@ def run_video(model, frames, target_fps, input_size=518, device="cuda", batch_si
 def _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_fn, shard_output, n, h0, w0, keep_on_device):
     clamp = bool(getattr(model, "clamp_input_size_on_gpu", False)) and dev.type == "cuda"
     H, W = network_size(h0, w0, input_size, clamp_420=clamp)
+    # a window starts with frames of the window before it: a model that can carry their encoder outputs over is told
+    # which video frame each slot holds
+    keyed = forward_fn is None and bool(getattr(model, "reuse_encoder_features", False))
     fwd = forward_fn or model.forward
+    if keyed:
+        model.reset_frame_cache()
     shard_output = shard_output or getattr(model, "shard_output", "replicate")
     if shard_output not in ("replicate", "local"):
         raise ValueError(f"shard_output {shard_output!r}: expected 'replicate' or 'local'")
@@ -206,7 +213,7 @@ def _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_f
     def raw_window(w):
         """Raw full-resolution depth [L, h0, w0] of window w."""
         x = src.window(frame_ids[w]).unsqueeze(0)
-        d = fwd(x).float().reshape(L, H, W).contiguous()
+        d = (fwd(x, frame_keys=frame_ids[w]) if keyed else fwd(x)).float().reshape(L, H, W).contiguous()
         if (H, W) == (h0, w0):
             return d
         out = torch.empty((L, h0, w0), dtype=torch.float32, device=dev)
@@ -277,6 +284,8 @@ def _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_f
                         prev_tail = [al.apply(tail[i], w) for i in range(INTERP_LEN)]
             pending = cur
 
+    if keyed:
+        model.reset_frame_cache()
     out = sink.result()
     owner = np.full(n, -1, dtype=np.int64)
     for w, (start, slot, cnt) in enumerate(runs):

@@ -57,9 +57,9 @@ class VideoDepthAnything(nn.Module):
         # rate as bf16 and 3 more mantissa bits; with bf16 here the depth error is 1.6e-2 max-relative (above the 1e-2
         # bound), with fp16 it is set by the bf16 encoder alone.  The reference's own GPU default is fp16 autocast.
         self.head_dtype = torch.float16
-        # "half": 16-bit activations (bf16 encoder, head_dtype head).  "fp32": fp32 activations and three-term bf16 hi/lo
-        # products on the same matrix cores (about 2^-16 per product) -- what ``infer_video_depth(fp32=True)`` selects,
-        # the counterpart of the reference running without autocast (video_depth.py:136).
+        # "half": 16-bit activations (bf16 encoder, head_dtype head).  "fp32": fp32 activations and three-term IEEE-half
+        # hi/lo products on the same matrix cores (about 2^-21 per product) -- what ``infer_video_depth(fp32=True)``
+        # selects, the counterpart of the reference running without autocast (video_depth.py:136).
         self.precision = "half"
         gen = torch.Generator().manual_seed(0)
         for key, (shape, kind) in state_dict_spec(encoder, features, self.out_channels, num_frames).items():
@@ -80,6 +80,10 @@ class VideoDepthAnything(nn.Module):
         # multi-rank infer_video_depth: "replicate" = every rank returns the whole video, "local" = a rank returns only the
         # frames of its own windows (zeros elsewhere; ``last_owned_frames`` is the mask) and no final frame is exchanged
         self.shard_output = "replicate"
+        # infer_video_depth: consecutive windows share ten of their 32 frames (video_depth.py:157-164) and the encoder treats
+        # frames one by one, so a window takes the encoder outputs of those frames from the window before it on this
+        # process instead of recomputing them (the temporal head still sees all 32).  False recomputes, like the reference.
+        self.reuse_encoder_features = True
         self._engines = {}            # precision -> (weights key, Engine)
         self._flat = None             # the parameter and buffer tensors, listed once (see _weights_key)
 
@@ -117,9 +121,18 @@ class VideoDepthAnything(nn.Module):
             self._engines[self.precision] = cached
         return cached[1]
 
+    def reset_frame_cache(self):
+        """Drop the encoder outputs kept by keyed forward calls (start and end of a video)."""
+        for _, eng in self._engines.values():
+            eng.kept = None
+
     @torch.no_grad()
-    def forward(self, x):
-        """``x[B, T, 3, H, W]`` (ImageNet-normalised RGB, H and W multiples of 14, T <= num_frames) -> ``[B, T, H, W]`` fp32."""
+    def forward(self, x, frame_keys=None):
+        """``x[B, T, 3, H, W]`` (ImageNet-normalised RGB, H and W multiples of 14, T <= num_frames) -> ``[B, T, H, W]`` fp32.
+
+        ``frame_keys`` (no counterpart in the reference; B = 1): one hashable identity per frame.  The leading frames whose
+        keys were also given to the previous keyed call take their encoder outputs from that call; the caller vouches that
+        equal keys mean equal pixels and calls ``reset_frame_cache()`` when the keys start to mean something else."""
         if x.dim() != 5 or x.shape[2] != 3:
             raise ValueError(f"expected input [B, T, 3, H, W], got {tuple(x.shape)}")
         B, T, _, H, W = x.shape
@@ -132,7 +145,7 @@ class VideoDepthAnything(nn.Module):
         eng = self._ensure_engine()
         eng.encoder_streams = self.encoder_streams
         with torch.cuda.device(x.device):
-            return eng.forward(x.float().contiguous())
+            return eng.forward(x.float().contiguous(), frame_keys)
 
     @torch.no_grad()
     def infer_video_depth(self, frames, target_fps, input_size=518, device="cuda", fp32=False, batch_size=16,

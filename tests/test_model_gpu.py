@@ -69,6 +69,45 @@ def test_whole_video_matches_reference_goldens(golden_dir, vits, n, bs, fp32):
     assert (mr <= MAX_REL and ar <= ABS_REL) if not fp32 else (mr <= FP32_MODE_MAX_REL and ar <= FP32_MODE_MAX_REL)
 
 
+@pytest.mark.parametrize("fp32", [False, True])
+def test_encoder_outputs_carried_between_windows_change_nothing(vits, fp32):
+    """A window takes the encoder outputs of the frames it shares with the window before it from that window.  The same
+    kernels ran on the same rows when those were computed, so the video comes out the same with the carry-over off."""
+    model, _ = vits
+    frames = synth_frames(77, 42, 56, 9)
+    assert model.reuse_encoder_features
+    a, _ = model.infer_video_depth(frames, 24, input_size=42, device="cuda", fp32=fp32, batch_size=32)
+    model.reuse_encoder_features = False
+    try:
+        b, _ = model.infer_video_depth(frames, 24, input_size=42, device="cuda", fp32=fp32, batch_size=32)
+    finally:
+        model.reuse_encoder_features = True
+    # a GEMM of 22 frames may run on another tile shape than one of 32 (sums in another order): rounding-level differences
+    assert np.abs(a - b).max() <= (2e-6 if fp32 else 2e-3) * np.abs(b).max()
+
+
+def test_keyed_forward_carries_only_the_leading_known_frames(vits):
+    model, _ = vits
+    x = torch.from_numpy(np.random.RandomState(3).standard_normal((1, 8, 3, 42, 42)).astype(np.float32)).cuda()
+    y = torch.from_numpy(np.random.RandomState(4).standard_normal((1, 8, 3, 42, 42)).astype(np.float32)).cuda()
+    y[0, 0], y[0, 1], y[0, 2], y[0, 5] = x[0, 0], x[0, 6], x[0, 7], x[0, 3]     # slot 5 is known too, but not leading
+    keys_x = [("v", i) for i in range(8)]
+    keys_y = [("v", 0), ("v", 6), ("v", 7), ("v", 20), ("v", 21), ("v", 3), ("v", 22), ("v", 23)]
+    want = model(y)
+    model.reset_frame_cache()
+    model(x, frame_keys=keys_x)
+    got = model(y, frame_keys=keys_y)
+    eng = model._ensure_engine()
+    assert eng.kept is not None and eng.kept["slot"][("v", 23)] == 7
+    assert (got - want).abs().max() <= 2e-3 * want.abs().max()
+    other = model(y.reshape(1, 8, 3, 42, 42)[:, :, :, :28].contiguous(), frame_keys=keys_y)      # another size: nothing carried
+    assert torch.equal(other, model(y[:, :, :, :28].contiguous()))
+    model.reset_frame_cache()
+    assert eng.kept is None
+    with pytest.raises(ValueError):
+        model(y, frame_keys=keys_y[:3])
+
+
 @pytest.mark.parametrize("name,shape,seed", [("T32", (1, 32, 3, 70, 98), 41), ("B2T3", (2, 3, 3, 56, 42), 43)])
 def test_forward_fp32_mode_matches_reference_goldens(golden_dir, vits, name, shape, seed):
     model, _ = vits
