@@ -272,12 +272,14 @@ def end_to_end(model, H, W, n=98):
     return res
 
 
-def sharded_video(model, H, W, world, rank, dev, barrier, rounds=4):
-    """One video through ``infer_video_depth`` with its windows dealt round-robin over the ranks: per round each rank
-    contributes 11 raw maps (slots 0, 1, 12 and 24..31 of its window) to one RCCL all-gather, replays the alignment chain,
-    aligns its own frames and copies them to its own host memory (``shard_output='local'``: no final frame is exchanged)."""
-    n = 22 * world * rounds               # exactly world * rounds windows
-    frames = np.random.RandomState(5).randint(0, 256, (n, H, W, 3), dtype=np.uint8)      # every rank holds the same video
+def sharded_video(model, H, W, world, rank, dev, barrier, windows_per_rank=12):
+    """One video through ``infer_video_depth`` with its windows dealt over the ranks in rounds of up to eight consecutive
+    windows per rank: per round each rank contributes 11 raw maps per window (slots 0, 1, 12 and 24..31) to one RCCL
+    all-gather, replays the alignment chain, aligns its own frames and copies them to its own host memory
+    (``shard_output='local'``: no final frame is exchanged)."""
+    n = 22 * world * windows_per_rank               # exactly world * windows_per_rank windows
+    base = np.random.RandomState(5).randint(0, 256, (64, H, W, 3), dtype=np.uint8)
+    frames = [base[i % 64] for i in range(n)]       # every rank holds the same video (a list of frames, 64 distinct ones)
     model.shard_output = "local"
     model.infer_video_depth(frames[:22 * world + 10], 30, input_size=min(H, W), device=str(dev), batch_size=32)      # warm-up
     barrier()
@@ -299,10 +301,12 @@ def sharded_video(model, H, W, world, rank, dev, barrier, rounds=4):
     return {"video_frames_per_s": round(n / dt, 2), "model_frames_per_s": round(32 * st["windows"] / dt, 2), "frames": n,
             "windows": st["windows"], "rounds": st["rounds"], "seconds": round(dt, 3), "ranks_seen": dist.get_world_size(),
             "backend": dist.get_backend(), "frames_owned_over_all_ranks": int(owned.item()),
-            "all_gathered_bytes_per_round": st["gathered_bytes_per_round"],
-            "all_gathered_bytes_per_window_per_rank": 11 * H * W * 4,
+            "all_gathered_bytes": st["gathered_bytes"],
+            "all_gathered_bytes_per_window_per_rank": st["gathered_bytes_per_window_per_rank"],
             "path": "host uint8 frames on every rank -> infer_video_depth(batch_size=32, shard_output='local') -> each rank's own "
-                    "frames in its host memory; collectives: one all-gather of 11 fp32 maps per rank and round"}
+                    "frames in its host memory; a rank runs blocks of up to 8 consecutive windows (the later ones take the "
+                    "encoder outputs of the 10 shared frames from the one before); collectives: one all-gather of 11 fp32 "
+                    "maps per window and rank per round"}
 
 
 def cpu_info():

@@ -7,13 +7,13 @@ Differences from the reference's data flow (results are the same function of the
     instead of recomputing them (``model.reuse_encoder_features``);
   * the full-resolution upsample, the least-squares alignment and the cross-fade run on the device; only final maps are
     copied back, from a side stream, into a small ring of pinned buffers, while the next window is computed;
-  * with ``torch.distributed`` initialised (one process per GPU, backend "nccl" = RCCL) the windows are dealt round-robin:
-    window w runs on rank w % world.  A window depends only on INPUT frames, so the ranks compute a round of ``world``
-    windows independently.  Per round each rank then contributes the eleven raw maps of its window that other ranks need
-    -- slots 0, 1, 12 (the alignment chain, video_depth.py:180-201) and slots 24..31 (the cross-fade partner of the next
-    window, :189) -- to ONE all-gather, issued asynchronously so that it travels while the next round is computed.
-    Every rank replays the round's cheap sequential fits, aligns the frames of its own window and streams them to its
-    host.  No final frame crosses the links unless the caller wants every rank to return the whole video
+  * with ``torch.distributed`` initialised (one process per GPU, backend "nccl" = RCCL) the windows are dealt in rounds:
+    per round a rank takes a block of up to eight consecutive windows (windows.schedule; consecutive, so that the carry-
+    over above works on every rank).  A window depends only on INPUT frames, so the ranks compute a round independently.
+    Per round each rank then contributes the eleven raw maps of each of its windows that other ranks need -- slots 0, 1,
+    12 (the alignment chain, video_depth.py:180-201) and slots 24..31 (the cross-fade partner of the next window, :189)
+    -- to ONE all-gather, issued asynchronously so that it travels while the next round is computed.  Every rank replays
+    the round's cheap sequential fits, aligns the frames of its own windows and streams them to its host.  No final frame crosses the links unless the caller wants every rank to return the whole video
     (``shard_output="replicate"``, the default, for drop-in callers; "local" keeps a rank's frames on that rank).
 """
 from collections import OrderedDict
@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import hip
-from .windows import INFER_LEN, INTERP_LEN, OVERLAP, Aligner, network_size, partition, resolve_plan, window_plan
+from .windows import BLOCK_MAX, INFER_LEN, INTERP_LEN, OVERLAP, Aligner, network_size, resolve_plan, schedule, window_plan
 
 KEY_SLOTS = (0, 1, 12)                      # raw maps of a window that the alignment chain reads
 PACK = len(KEY_SLOTS) + INTERP_LEN          # maps a rank contributes per round: the key maps and the 8-map tail
@@ -208,7 +208,15 @@ def _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_f
     if keep_on_device and world > 1 and shard_output != "local":
         raise ValueError("keep_on_device with several ranks needs shard_output='local' (a rank keeps its own frames)")
     sink = DeviceSink(n, h0, w0, dev) if keep_on_device else HostSink(n, h0, w0, dev)
-    stats = dict(world=world, windows=n_win, rounds=-(-n_win // world), gathered_bytes_per_round=0)
+    # several ranks: a rank takes a block of consecutive windows per round (they share frames, see schedule); one process
+    # finishes window by window; unaligned windows need no rounds at all
+    if not stitched:
+        rounds = schedule(n_win, world, n_win)
+    else:
+        rounds = schedule(n_win, world, int(getattr(model, "shard_block", BLOCK_MAX)) if world > 1 else 1)
+    owner_of = {w: j for rd in rounds for j, ws in enumerate(rd) for w in ws}
+    stats = dict(world=world, windows=n_win, rounds=len(rounds), gathered_bytes=0,
+                 gathered_bytes_per_window_per_rank=PACK * h0 * w0 * 4 if world > 1 else 0)
 
     def raw_window(w):
         """Raw full-resolution depth [L, h0, w0] of window w."""
@@ -221,67 +229,66 @@ def _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_f
         return out
 
     if not stitched:        # reference quirk: overlapping windows concatenated unaligned; nothing to exchange
-        for w in partition(n_win, world, rank):
+        for w in rounds[0][rank]:
             d = raw_window(w)
             start, slot, cnt = runs[w]
             sink.push(start, [d[slot + i] for i in range(cnt)])
     else:
         al = Aligner(dev)
-        prev_tail = None                  # aligned slots 24..31 of the window before the next one to be finished
+        prev_tail = None                  # aligned slots 24..31 of the window before the next one this rank finishes
         pending = None
-        rounds = stats["rounds"]
-        if world > 1:
-            stats["gathered_bytes_per_round"] = world * PACK * h0 * w0 * 4
-        for rd in range(rounds + 1):
+        for rd in range(len(rounds) + 1):
             cur = None
-            if rd < rounds:
-                w = rd * world + rank
-                d = raw_window(w) if w < n_win else None
+            if rd < len(rounds):
+                mine = rounds[rd][rank]
+                block = max(len(ws) for ws in rounds[rd])
+                ds = [raw_window(w) for w in mine]
                 if world > 1:
-                    pack = torch.zeros((PACK, h0, w0), dtype=torch.float32, device=dev)
-                    if d is not None:
+                    pack = torch.zeros((block * PACK, h0, w0), dtype=torch.float32, device=dev)
+                    for b, d in enumerate(ds):
                         for j, s in enumerate(KEY_SLOTS):
-                            pack[j] = d[s]
-                        pack[len(KEY_SLOTS):] = d[INFER_LEN - INTERP_LEN:]
+                            pack[b * PACK + j] = d[s]
+                        pack[b * PACK + len(KEY_SLOTS):(b + 1) * PACK] = d[INFER_LEN - INTERP_LEN:]
                     # the overlap maps only; asynchronous: it travels while the next round's windows are computed
-                    packs = torch.empty((world, PACK, h0, w0), dtype=torch.float32, device=dev)
+                    packs = torch.empty((world, block * PACK, h0, w0), dtype=torch.float32, device=dev)
+                    stats["gathered_bytes"] += packs.numel() * 4
                     if dist.get_backend() == "nccl":
                         work = dist.all_gather_into_tensor(packs, pack, async_op=True)
                     else:       # other backends (gloo in tests and single-GPU rehearsals): blocking, through host memory
                         work = None
-                        parts = [torch.empty((PACK, h0, w0), dtype=torch.float32) for _ in range(world)]
+                        parts = [torch.empty((block * PACK, h0, w0), dtype=torch.float32) for _ in range(world)]
                         dist.all_gather(parts, pack.cpu())
                         packs.copy_(torch.stack(parts, 0))
                 else:
                     packs, work = None, None
-                cur = (rd, d, packs, work)
+                cur = (rd, ds, packs, work)
             if pending is not None:
-                prd, pd, ppacks, pwork = pending
+                prd, pds, ppacks, pwork = pending
                 if pwork is not None:
                     pwork.wait()
                 for j in range(world):
-                    w = prd * world + j
-                    if w >= n_win:
-                        break
-                    mine = j == rank
-                    if world > 1:
-                        keys, tail = ppacks[j, :len(KEY_SLOTS)], ppacks[j, len(KEY_SLOTS):]
-                    else:
-                        keys, tail = [pd[s] for s in KEY_SLOTS], pd[INFER_LEN - INTERP_LEN:]
-                    al.advance(w, keys[0], keys[1], keys[2])
-                    if mine:
-                        start, slot, cnt = runs[w]
-                        final = []
-                        for i in range(cnt):
-                            s = slot + i
-                            if w > 0 and s < OVERLAP:          # slots 2..9: cross-fade onto the previous window's tail
-                                final.append(al.blend(pd[s], prev_tail[s - (OVERLAP - INTERP_LEN)], s - (OVERLAP - INTERP_LEN)))
-                            else:
-                                final.append(al.apply(pd[s], w))
-                        sink.push(start, final)
-                    # the aligned tail of window w is read by the owner of window w + 1
-                    if w + 1 < n_win and (j + 1) % world == rank:
-                        prev_tail = [al.apply(tail[i], w) for i in range(INTERP_LEN)]
+                    for b, w in enumerate(rounds[prd][j]):
+                        own = j == rank
+                        if world > 1:
+                            keys = ppacks[j, b * PACK:b * PACK + len(KEY_SLOTS)]
+                            tail = ppacks[j, b * PACK + len(KEY_SLOTS):(b + 1) * PACK]
+                        else:
+                            keys, tail = [pds[b][s] for s in KEY_SLOTS], pds[b][INFER_LEN - INTERP_LEN:]
+                        al.advance(w, keys[0], keys[1], keys[2])
+                        if own:
+                            pd = pds[b]
+                            start, slot, cnt = runs[w]
+                            final = []
+                            for i in range(cnt):
+                                s = slot + i
+                                if w > 0 and s < OVERLAP:          # slots 2..9: cross-fade onto the previous window's tail
+                                    final.append(al.blend(pd[s], prev_tail[s - (OVERLAP - INTERP_LEN)], s - (OVERLAP - INTERP_LEN)))
+                                else:
+                                    final.append(al.apply(pd[s], w))
+                            sink.push(start, final)
+                        # the aligned tail of window w is read by the owner of window w + 1
+                        if w + 1 < n_win and owner_of[w + 1] == rank:
+                            prev_tail = [al.apply(tail[i], w) for i in range(INTERP_LEN)]
             pending = cur
 
     if keyed:
@@ -289,7 +296,7 @@ def _run_video(model, frames, target_fps, input_size, dev, batch_size, forward_f
     out = sink.result()
     owner = np.full(n, -1, dtype=np.int64)
     for w, (start, slot, cnt) in enumerate(runs):
-        owner[start:start + cnt] = w % world
+        owner[start:start + cnt] = owner_of[w]
     if model is not None:
         model.last_owned_frames = owner == rank
         model.last_shard_stats = stats

@@ -80,6 +80,8 @@ class VideoDepthAnything(nn.Module):
         # multi-rank infer_video_depth: "replicate" = every rank returns the whole video, "local" = a rank returns only the
         # frames of its own windows (zeros elsewhere; ``last_owned_frames`` is the mask) and no final frame is exchanged
         self.shard_output = "replicate"
+        # multi-rank infer_video_depth: consecutive windows a rank takes per round (windows.schedule); 1 = round-robin
+        self.shard_block = 8
         # infer_video_depth: consecutive windows share ten of their 32 frames (video_depth.py:157-164) and the encoder treats
         # frames one by one, so a window takes the encoder outputs of those frames from the window before it on this
         # process instead of recomputing them (the temporal head still sees all 32).  False recomputes, like the reference.

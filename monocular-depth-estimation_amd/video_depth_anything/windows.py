@@ -72,10 +72,24 @@ def resolve_plan(plan):
     return out
 
 
-def partition(n_windows, world, rank):
-    """The windows of ``rank``: window w runs on rank w % world, so that the windows of one round (world consecutive
-    windows) finish together and the sequential alignment can follow round by round."""
-    return list(range(rank, n_windows, world))
+BLOCK_MAX = 8      # consecutive windows a rank takes per round (see schedule)
+
+
+def schedule(n_windows, world, block_max=BLOCK_MAX):
+    """Which rank runs which window, round by round: ``rounds[r][rank]`` is a (possibly empty) run of consecutive windows.
+
+    A rank takes up to ``block_max`` CONSECUTIVE windows per round, because consecutive windows share ten of their 32
+    frames and the second of them can take those frames' encoder outputs from the first.  The block of a round is no
+    longer than an even split of what is left, so a short video still occupies every rank: with ``b = min(block_max,
+    ceil(left / world))`` rank j takes windows ``first + j*b .. first + (j+1)*b - 1`` of the round.  All windows of a round
+    finish together, and the sequential alignment follows round by round.  ``block_max = 1`` is plain round-robin."""
+    rounds, first = [], 0
+    while first < n_windows:
+        left = n_windows - first
+        b = max(1, min(block_max, -(-left // world)))
+        rounds.append([list(range(min(first + j * b, n_windows), min(first + (j + 1) * b, n_windows))) for j in range(world)])
+        first += min(left, world * b)
+    return rounds
 
 
 class Aligner:

@@ -53,12 +53,22 @@ def test_window_plan_matches_oracle_and_closed_form(n, bs):
             assert w == [min(i, n - 1) for i in want]
 
 
-def test_partition_covers_all_windows():
-    for n in (1, 5, 8, 9, 137):
+def test_schedule_covers_all_windows_in_order_with_consecutive_blocks():
+    for n in (1, 5, 8, 9, 23, 100, 137):
         for world in (1, 2, 3, 8):
-            parts = [windows.partition(n, world, r) for r in range(world)]
-            assert sorted(w for p in parts for w in p) == list(range(n))
-            assert all(w % world == r for r, p in enumerate(parts) for w in p)      # round-robin: a round finishes together
+            for block in (1, 3, 8):
+                rounds = windows.schedule(n, world, block)
+                flat = [w for rd in rounds for ws in rd for w in ws]
+                assert flat == list(range(n))                                   # rounds, and ranks within a round, in window order
+                assert all(len(rd) == world and all(len(ws) <= block for ws in rd) for rd in rounds)
+                assert all(ws == list(range(ws[0], ws[0] + len(ws))) for rd in rounds for ws in rd if ws)
+                # a round's block is an even split of what is left: no rank idles while another holds two windows more
+                for rd in rounds[:-1]:
+                    assert len({len(ws) for ws in rd}) == 1
+                sizes = [len(ws) for ws in rounds[-1]]
+                assert sizes == sorted(sizes, reverse=True) and sizes.count(max(sizes)) >= len([v for v in sizes if v]) - 1
+    assert windows.schedule(7, 3, 1) == [[[0], [1], [2]], [[3], [4], [5]], [[6], [], []]]
+    assert windows.schedule(5, 2) == [[[0, 1, 2], [3, 4]]]
 
 
 @pytest.mark.parametrize("enc", ["vits", "vitl"])
@@ -165,7 +175,15 @@ frames = T.frames_for(120, 28, 42, 120)
 got, _ = pipeline.run_video(holder, frames, 25, input_size=28, device="cpu", batch_size=32, forward_fn=T.fake_forward, shard_output="local")
 np.save(os.path.join({out!r}, f"local{{dist.get_rank()}}.npy"), got)
 np.save(os.path.join({out!r}, f"owned{{dist.get_rank()}}.npy"), holder.last_owned_frames)
-assert holder.last_shard_stats["gathered_bytes_per_round"] == dist.get_world_size() * 11 * 28 * 42 * 4
+st = holder.last_shard_stats
+assert st["gathered_bytes_per_window_per_rank"] == 11 * 28 * 42 * 4
+blocks = [max(len(ws) for ws in rd) for rd in T.windows.schedule(st["windows"], dist.get_world_size())]
+assert st["gathered_bytes"] == sum(blocks) * dist.get_world_size() * 11 * 28 * 42 * 4 and st["rounds"] == len(blocks)
+holder.shard_block = 1          # plain round-robin: one window per rank and round
+got1, _ = pipeline.run_video(holder, frames, 25, input_size=28, device="cpu", batch_size=32, forward_fn=T.fake_forward, shard_output="local")
+assert holder.last_shard_stats["rounds"] == -(-st["windows"] // dist.get_world_size())
+np.save(os.path.join({out!r}, f"local_rr{{dist.get_rank()}}.npy"), got1)
+np.save(os.path.join({out!r}, f"owned_rr{{dist.get_rank()}}.npy"), holder.last_owned_frames)
 dist.barrier()
 """
 
@@ -189,10 +207,11 @@ def test_window_sharded_pipeline_over_gloo_matches_single_process(tmp_path, worl
             got = np.load(tmp_path / f"r{r}_{n}_{bs}.npy")
             assert got.shape == want.shape
             assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), (n, bs, r)
-    # shard_output="local": disjoint parts that cover the video; eleven maps per rank and round are exchanged, no final frame
+    # shard_output="local": disjoint parts that cover the video; eleven maps per window are exchanged, no final frame
     want = O.infer_video_depth(None, list(frames_for(120, 28, 42, 120)), "vits", batch_size=32, forward_fn=fake_forward)
-    masks = np.stack([np.load(tmp_path / f"owned{r}.npy") for r in range(world)])
-    assert (masks.sum(0) == 1).all()
-    for r in range(world):
-        got = np.load(tmp_path / f"local{r}.npy")
-        assert np.abs(got[masks[r]] - want[masks[r]]).max() <= 2e-5 * np.abs(want).max() and not got[~masks[r]].any()
+    for tag in ("", "_rr"):                 # blocks of consecutive windows per rank (default), and plain round-robin
+        masks = np.stack([np.load(tmp_path / f"owned{tag}{r}.npy") for r in range(world)])
+        assert (masks.sum(0) == 1).all()
+        for r in range(world):
+            got = np.load(tmp_path / f"local{tag}{r}.npy")
+            assert np.abs(got[masks[r]] - want[masks[r]]).max() <= 2e-5 * np.abs(want).max() and not got[~masks[r]].any()
