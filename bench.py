@@ -192,9 +192,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_vits and args.encoder == "vitl":
         out["vits"] = vits_line(build, timed_steps, kernel_pass, roofline_of, args, dev)
     if world == 1 and not args.no_end_to_end:
-        out["end_to_end"] = end_to_end(model, H, W)
+        try:
+            out["end_to_end"] = end_to_end(model, H, W)
+        except Exception as e:      # noqa: BLE001
+            out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if world > 1 and not args.no_sharded_video:
-        sv = sharded_video(model, H, W, world, rank, dev, barrier)
+        try:        # an auxiliary block: a failure in it must not cost the run its headline line
+            sv = sharded_video(model, H, W, world, rank, dev, barrier)
+        except Exception as e:      # noqa: BLE001  (reported in the line, not swallowed)
+            sv = {"error": f"{type(e).__name__}: {e}"[:400]}
         if rank == 0:
             out["sharded_video"] = sv
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
