@@ -34,6 +34,7 @@ class Engine:
         self.act_scale = ACT_SPLIT_SCALE if SPLIT_DTYPE == torch.float16 else 1.0
         self.encoder_streams = 2      # frame groups of the encoder that run on concurrent streams (see encoder())
         self.side_streams = []
+        self.head_streams = 2         # 2: the head's high-resolution branches run on the first side stream (see head())
         self.kept = None              # encoder outputs of the last keyed forward() (see forward)
 
     # ---- small wrappers -------------------------------------------------------------------------------------------
@@ -244,20 +245,44 @@ class Engine:
             p = _empty((frames * hw, w.ocp[i]), self.hdt, dev)
             self.linear(taps[i], w.proj_w[i], p, w.proj_b[i])
             proj.append(p)
-        l1 = _empty((frames, 4 * hp, 4 * wp, w.ocp[0]), self.hdt, dev)
-        self.linear(proj[0], w.rs0_w, l1, w.rs0_b, N=16 * w.ocp[0], ldc=w.ocp[0], epi=hip.EPI_CONVT, convt=(hp, wp, 4, w.ocp[0]))
-        l2 = _empty((frames, 2 * hp, 2 * wp, w.ocp[1]), self.hdt, dev)
-        self.linear(proj[1], w.rs1_w, l2, w.rs1_b, N=4 * w.ocp[1], ldc=w.ocp[1], epi=hip.EPI_CONVT, convt=(hp, wp, 2, w.ocp[1]))
-        l3 = proj[2].reshape(frames, hp, wp, w.ocp[2])
+        # The four pyramid branches are independent until the fusion blocks join them, the coarsest first.  The coarsest
+        # branch (stride-2 conv, temporal module, fusion block, temporal module: 19 x 19 and 37 x 37 maps, grids that fill a
+        # fraction of the CUs) stays on the caller's stream; the other three, with their large kernels, run beside it on a
+        # side stream until the first fusion block that needs them.  Outputs that cross streams are allocated here, on the
+        # caller's stream.
+        r1 = _empty((frames, 4 * hp, 4 * wp, w.Fp), self.hdt, dev)
+        r2 = _empty((frames, 2 * hp, 2 * wp, w.Fp), self.hdt, dev)
+        r3 = _empty((frames, hp, wp, w.Fp), self.hdt, dev)
+
+        def other_branches():
+            l1 = _empty((frames, 4 * hp, 4 * wp, w.ocp[0]), self.hdt, dev)
+            self.linear(proj[0], w.rs0_w, l1, w.rs0_b, N=16 * w.ocp[0], ldc=w.ocp[0], epi=hip.EPI_CONVT, convt=(hp, wp, 4, w.ocp[0]))
+            l2 = _empty((frames, 2 * hp, 2 * wp, w.ocp[1]), self.hdt, dev)
+            self.linear(proj[1], w.rs1_w, l2, w.rs1_b, N=4 * w.ocp[1], ldc=w.ocp[1], epi=hip.EPI_CONVT, convt=(hp, wp, 2, w.ocp[1]))
+            self.conv3(l1, w.rn_w[0], None, w.Fp, out=r1)
+            self.conv3(l2, w.rn_w[1], None, w.Fp, out=r2)
+            l3 = self.motion(0, proj[2].reshape(frames, hp, wp, w.ocp[2]), B, T)
+            self.conv3(l3, w.rn_w[2], None, w.Fp, out=r3)
+
+        joined = None
+        if self.head_streams > 1 and self.encoder_streams > 1 and self.side_streams:
+            main, side = torch.cuda.current_stream(), self.side_streams[0]
+            fork = torch.cuda.Event()
+            fork.record(main)
+            side.wait_event(fork)                     # the projections and r1, r2, r3 exist
+            with torch.cuda.stream(side):
+                other_branches()
+                joined = torch.cuda.Event()
+                joined.record(side)
+        else:
+            other_branches()
         l4 = self.conv3(proj[3].reshape(frames, hp, wp, w.ocp[3]), w.rs3_w, w.rs3_b, w.ocp[3], stride=2)
-        l3 = self.motion(0, l3, B, T)
         l4 = self.motion(1, l4, B, T)
-        r1 = self.conv3(l1, w.rn_w[0], None, w.Fp)
-        r2 = self.conv3(l2, w.rn_w[1], None, w.Fp)
-        r3 = self.conv3(l3, w.rn_w[2], None, w.Fp)
         r4 = self.conv3(l4, w.rn_w[3], None, w.Fp)
         p4 = self.fusion(4, r4, None, hp, wp)
         p4 = self.motion(2, p4, B, T)
+        if joined is not None:
+            torch.cuda.current_stream().wait_event(joined)
         p3 = self.fusion(3, p4, r3, 2 * hp, 2 * wp)
         p3 = self.motion(3, p3, B, T)
         p2 = self.fusion(2, p3, r2, 4 * hp, 4 * wp)

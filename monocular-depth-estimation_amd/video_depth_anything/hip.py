@@ -117,6 +117,8 @@ def zero_page(device):
     z = _zeros.get(device)
     if z is None:
         z = torch.zeros(256, dtype=torch.uint8, device=device)
+        # filled on whichever stream is current now, read from then on by launches on every stream: wait for the fill once
+        torch.cuda.current_stream(z.device).synchronize()
         _zeros[device] = z
     return z
 

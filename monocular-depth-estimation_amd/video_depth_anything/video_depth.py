@@ -77,6 +77,8 @@ class VideoDepthAnything(nn.Module):
             _install(self, key, t, buffer=(kind == "pe"))
         # frame groups of the encoder that run on concurrent HIP streams (see Engine.encoder)
         self.encoder_streams = int(os.environ.get("VDA_ENCODER_STREAMS", "2"))
+        # 2: the DPT head's two high-resolution branches run beside its low-resolution ones on a second stream (Engine.head)
+        self.head_streams = int(os.environ.get("VDA_HEAD_STREAMS", "2"))
         # multi-rank infer_video_depth: "replicate" = every rank returns the whole video, "local" = a rank returns only the
         # frames of its own windows (zeros elsewhere; ``last_owned_frames`` is the mask) and no final frame is exchanged
         self.shard_output = "replicate"
@@ -146,6 +148,7 @@ class VideoDepthAnything(nn.Module):
             raise RuntimeError("forward() needs a device tensor: the MI355X build has no CPU path")
         eng = self._ensure_engine()
         eng.encoder_streams = self.encoder_streams
+        eng.head_streams = self.head_streams
         with torch.cuda.device(x.device):
             return eng.forward(x.float().contiguous(), frame_keys)
 
