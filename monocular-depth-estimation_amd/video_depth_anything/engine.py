@@ -34,7 +34,7 @@ class Engine:
         self.act_scale = ACT_SPLIT_SCALE if SPLIT_DTYPE == torch.float16 else 1.0
         self.encoder_streams = 2      # frame groups of the encoder that run on concurrent streams (see encoder())
         self.side_streams = []
-        self.head_streams = 2         # 2: the head's high-resolution branches run on the first side stream (see head())
+        self.head_streams = 2         # 2: parts of the head run on the first side stream beside the rest (see head())
         self.kept = None              # encoder outputs of the last keyed forward() (see forward)
 
     # ---- small wrappers -------------------------------------------------------------------------------------------
@@ -285,13 +285,32 @@ class Engine:
             torch.cuda.current_stream().wait_event(joined)
         p3 = self.fusion(3, p4, r3, 2 * hp, 2 * wp)
         p3 = self.motion(3, p3, B, T)
-        p2 = self.fusion(2, p3, r2, 4 * hp, 4 * wp)
-        # the two largest resamplings (to 8x and 14x the patch grid) are folded into the convolutions that read them
-        p1 = self.fusion(1, p2, r1, 8 * hp, 8 * wp, resize=False)
-        o1 = self.conv3(p1, w.oc1_w, w.oc1_b, w.F2p, resized=(8 * hp, 8 * wp))
+        # From here on every stage works frame by frame (two fusion blocks, the output convolutions): two halves of the
+        # frames on the two streams, as in the encoder.
         depth = _empty((frames, 14 * hp, 14 * wp), torch.float32, dev)
-        self.conv3(o1, w.oc2_w, w.oc2_b, 32, out=depth, ldc=4, epi=hip.EPI_DOT, dot_w=w.dot_w, dot_b=w.dot_b,
-                   resized=(14 * hp, 14 * wp))
+
+        def tail(f0, f1):
+            p2 = self.fusion(2, p3[f0:f1], r2[f0:f1], 4 * hp, 4 * wp)
+            # the two largest resamplings (to 8x and 14x the patch grid) are folded into the convolutions that read them
+            p1 = self.fusion(1, p2, r1[f0:f1], 8 * hp, 8 * wp, resize=False)
+            o1 = self.conv3(p1, w.oc1_w, w.oc1_b, w.F2p, resized=(8 * hp, 8 * wp))
+            self.conv3(o1, w.oc2_w, w.oc2_b, 32, out=depth[f0:f1], ldc=4, epi=hip.EPI_DOT, dot_w=w.dot_w, dot_b=w.dot_b,
+                       resized=(14 * hp, 14 * wp))
+
+        if joined is not None and frames > 1:
+            main, side = torch.cuda.current_stream(), self.side_streams[0]
+            half = frames // 2
+            fork = torch.cuda.Event()
+            fork.record(main)
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                tail(half, frames)
+                done = torch.cuda.Event()
+                done.record(side)
+            tail(0, half)
+            main.wait_event(done)
+        else:
+            tail(0, frames)
         return depth
 
     def forward(self, x, frame_keys=None):

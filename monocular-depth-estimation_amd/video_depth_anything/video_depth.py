@@ -77,7 +77,7 @@ class VideoDepthAnything(nn.Module):
             _install(self, key, t, buffer=(kind == "pe"))
         # frame groups of the encoder that run on concurrent HIP streams (see Engine.encoder)
         self.encoder_streams = int(os.environ.get("VDA_ENCODER_STREAMS", "2"))
-        # 2: the DPT head's two high-resolution branches run beside its low-resolution ones on a second stream (Engine.head)
+        # 2: independent parts of the DPT head run side by side on two streams (Engine.head); 1: everything on the caller's
         self.head_streams = int(os.environ.get("VDA_HEAD_STREAMS", "2"))
         # multi-rank infer_video_depth: "replicate" = every rank returns the whole video, "local" = a rank returns only the
         # frames of its own windows (zeros elsewhere; ``last_owned_frames`` is the mask) and no final frame is exchanged
