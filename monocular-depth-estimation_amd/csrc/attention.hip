@@ -136,11 +136,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
             for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[b][0][i]);
 #pragma unroll
             for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[b][1][i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
             // Everything accumulated so far (o, l_run) is at scale 2^-m_run.  Move to a new maximum only if some query of the
             // block needs it (wave-uniform branch; always on the first tile, which sets the maximum whatever its sign); this
-            // tile's scores, already relative to the old maximum, move with it.
+            // tile's scores, already relative to the old maximum, move with it.  A query's keys are split over lanes r and
+            // r + 32: the vote sees both halves, so the two only have to agree on the maximum inside the branch.
             if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > DEFER) != 0) {
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
                 const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
                 const float alpha = kt == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
                 m_run[b] += delta;
@@ -324,8 +325,8 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restr
         for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (__builtin_amdgcn_ballot_w64(mx - m_run > DEFER) != 0) {
+        if (__builtin_amdgcn_ballot_w64(mx - m_run > DEFER) != 0) {      // the vote sees both lanes of a query
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
