@@ -70,6 +70,26 @@ def test_whole_video_matches_reference_goldens(golden_dir, vits, n, bs, fp32):
 
 
 @pytest.mark.parametrize("fp32", [False, True])
+def test_concurrent_streams_do_not_change_a_bit(vits, fp32):
+    """The encoder's frame groups and the head's branches run on two HIP streams; the launches and their operands are the
+    same as on one stream, so the results are too.  Repeated, because a missing dependency shows up as an occasional
+    difference, not a constant one."""
+    model, _ = vits
+    x = torch.from_numpy(np.random.RandomState(12).standard_normal((1, 32, 3, 70, 98)).astype(np.float32)).cuda()
+    saved = model.encoder_streams, model.head_streams, model.precision
+    try:
+        model.precision = "fp32" if fp32 else "half"
+        model.encoder_streams, model.head_streams = 1, 1
+        want = model(x).clone()
+        for enc, head in ((2, 2), (2, 1), (3, 2)):
+            model.encoder_streams, model.head_streams = enc, head
+            for _ in range(3):
+                assert torch.equal(model(x), want), (enc, head)
+    finally:
+        model.encoder_streams, model.head_streams, model.precision = saved
+
+
+@pytest.mark.parametrize("fp32", [False, True])
 def test_encoder_outputs_carried_between_windows_change_nothing(vits, fp32):
     """A window takes the encoder outputs of the frames it shares with the window before it from that window.  The same
     kernels ran on the same rows when those were computed, so the video comes out the same with the carry-over off."""
