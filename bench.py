@@ -10,8 +10,8 @@ collective); the reported value is all ranks' frames divided by the slowest rank
 The JSON line also carries
   roofline      : the dominant kernel (the 256x256-tile bf16 MFMA GEMM in the instantiation of the proj / fc2 products) timed
                   per launch with HIP events on the stream it is launched on: algorithmic FLOP per launch / average launch
-                  time vs the dense bf16 peak.  In the timed steps the encoder's two frame groups run on two streams and
-                  their launches overlap, so these times come from a second pass of the same K steps with the groups on
+                  time vs the dense bf16 peak.  In the timed steps the encoder's two frame groups (and the head's independent
+                  branches) run on two streams and their launches overlap, so these times come from a second pass of the same K steps with the groups on
                   one stream (``--encoder-streams 1`` runs the whole bench that way, as the committed rocprof summary does);
   vits          : the same measurement for VDA-Small (the metric names both models), N = 1 only;
   end_to_end    : the whole-video path (`infer_video_depth`) from host frames to host depth, PCIe included (N = 1 only);
