@@ -16,8 +16,10 @@
 // barrier; MFMAs; barrier (the buffers may be refilled).
 //
 // Fused upsampling (UP): the convolution input is the bilinear (align_corners) resampling of a smaller map.  The halo is
-// then not copied but computed: each lane loads the four source pixels of its 16-byte piece, blends them in fp32 and
-// writes the piece to the same LDS slot, so the resampled map (4 - 12 x the source) is never written to or read from HBM.
+// then not copied but computed: each lane blends the four source pixels of its 16-byte piece in fp32 and writes the piece
+// to the same LDS slot, so the resampled map (4 - 12 x the source) is never written to or read from HBM.  The four pixels
+// come straight from global memory, or (fp16 maps, scales <= 0.9 x 1) from the source patch that global_load_lds has
+// parked in the halo area first.
 //
 // LDS images are lane-linear (global_load_lds); halo pixel hp keeps its 16-byte channel chunk c at slot c ^ (hp & 7),
 // which is conflict-free for the ds_read_b128 lane groups at any starting pixel of a 16-pixel run; weight rows use the
@@ -106,7 +108,7 @@ __device__ __forceinline__ u32x4 blend2<bf16>(const u32x4& a, const u32x4& b, fl
 }
 
 template <int TN, int TPS, bool RELU_IN, bool UP, int SPEC, typename T>
-__global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs pa, const int tiles_x, const int tiles_y, const int two_pass) {
+__global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs pa, const int tiles_x, const int tiles_y, const int parked) {
     const VdaGemmArgs p = epi_spec_args<SPEC, T>(pa);          // the epilogue's choices as constants (EPI_SPEC_*)
     typedef typename Vec<T>::v8 frag_t;
     constexpr int N = TN * 16;
@@ -200,64 +202,69 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the writes have landed before this wave reaches the barrier
     };
-    // UP, horizontal scale <= 0.9 (the patch's 34 columns then come from at most 32 source columns): separable form with a
-    // third of the global loads.  Pass 1 blends the two source rows of every halo row for the source columns the patch
-    // touches and parks the result in the first columns of that halo row; pass 2 reads two parked columns per piece, and
-    // after a barrier (the expansion is in place) writes the final piece.  The parked values are rounded to T, so a halo
-    // value carries two roundings here instead of one.
-    auto blend_halo_2pass = [&](int cc) {
+    // UP, both scales such that the patch's 10 x 34 halo comes from at most 11 source rows x 32 source columns (vertical
+    // scale <= 1, horizontal <= 0.9): the source patch itself is copied into the halo area by global_load_lds, one source
+    // row of 32 pixels x 8 chunks per instruction -- a third of the loads of the four-tap form, no registers, ONE round of
+    // memory latency however few registers the accumulators leave -- and every halo piece is then blended from four LDS
+    // reads with the four-tap form's arithmetic (one rounding).  In place: all pieces are formed before any is written.
+    auto blend_halo_parked = [&](int cc) {
         const unsigned px_step = p.cin * sizeof(T), row_step = src_w * px_step;
         const char* a_cc = reinterpret_cast<const char*>(a_img) + cc * 128;
-        const int xs0 = (int)(up_sx * (float)max(ox0 - 1, 0));                          // first source column of the patch
-        const int xs_last = min((int)(up_sx * (float)min(ox0 + PT_W, p.in_w - 1)) + 1, src_w - 1);
-        const int ncol = xs_last - xs0 + 1;                                           // <= 32
+        const int iy_lo = max(oy0 - 1, 0), iy_hi = min(oy0 + PT_H, p.in_h - 1);
+        const int ix_lo = max(ox0 - 1, 0), ix_hi = min(ox0 + PT_W, p.in_w - 1);
+        const int xs0 = (int)(up_sx * (float)ix_lo), ys0 = (int)(up_sy * (float)iy_lo);
+        const int ncol = min((int)(up_sx * (float)ix_hi) + 1, src_w - 1) - xs0 + 1;            // <= 32
+        const int nrow = min((int)(up_sy * (float)iy_hi) + 1, src_h - 1) - ys0 + 1;            // <= 11
         {
-            const int c = tid >> 3, chunk = tid & 7;
-            const bool col_ok = c < ncol;
-            const unsigned col_off = (unsigned)(xs0 + (col_ok ? c : 0)) * px_step + (chunk << 4);
-            constexpr int RG = TN >= 8 ? 2 : TN >= 4 ? 5 : 10;                                   // halo rows whose loads fly together
-#pragma unroll 1
-            for (int r0 = 0; r0 < HALO_H; r0 += RG) {
-                u32x4 top[RG], bot[RG];
-                float wy[RG];
-#pragma unroll
-                for (int r = 0; r < RG; ++r) {
-                    const int iy = min(max(oy0 + r0 + r - 1, 0), p.in_h - 1);         // rows outside the image: any row
-                    const float fy = up_sy * (float)iy;
-                    const int y0 = (int)fy;
-                    wy[r] = fy - (float)y0;
-                    const unsigned o0 = (unsigned)y0 * row_step + col_off;
-                    top[r] = *reinterpret_cast<const u32x4*>(a_cc + o0);
-                    bot[r] = *reinterpret_cast<const u32x4*>(a_cc + (o0 + (y0 < src_h - 1 ? row_step : 0)));
-                }
-#pragma unroll
-                for (int r = 0; r < RG; ++r) {
-                    const int hpv = (r0 + r) * HALO_W + c;
-                    const u32x4 v = blend2<T>(top[r], bot[r], 1.f - wy[r], wy[r]);
-                    if (col_ok) *reinterpret_cast<u32x4*>(halo + hpv * 128 + ((chunk ^ (hpv & 7)) << 4)) = v;
-                }
-            }
+            const int sc = tid >> 3, slot = tid & 7;
+            const unsigned col_off = (unsigned)(xs0 + min(sc, ncol - 1)) * px_step + ((slot ^ (sc & 7)) << 4);
+            for (int it = 0; it < nrow; ++it)
+                glds16(a_cc + ((unsigned)(ys0 + it) * row_step + col_off), halo + (it * 256 + wave * 64) * 16);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (also the weights of this step, needed next anyway)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         u32x4 res[HALO_ITERS];
+        constexpr int G = TN >= 8 ? 2 : 4;                   // pieces whose four reads each are in flight together (registers)
+        // The positions and weights below do not depend on the channel slice.  Left alone the compiler computes them once,
+        // outside the slice loop, and keeps some hundred values live across the MFMA steps: make them depend on this call.
+        int t_id = tid;
+        asm volatile("" : "+v"(t_id));
 #pragma unroll
-        for (int it = 0; it < HALO_ITERS; ++it) {
-            const int piece = it * 256 + tid;
-            const int hp = piece >> 3, chunk = (piece & 7) ^ (hp & 7);
-            const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-            const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-            const bool ok = hp < HALO_PX && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
-            const float fx = up_sx * (float)(ok ? ix : 0);
-            const int x0 = (int)fx;
-            const float wx = fx - (float)x0;
-            const int row = (ok ? hy : 0) * HALO_W;
-            const int h0 = row + max(x0 - xs0, 0), h1 = row + max(min(x0 + 1, src_w - 1) - xs0, 0);
-            const u32x4 a = *reinterpret_cast<const u32x4*>(halo + h0 * 128 + ((chunk ^ (h0 & 7)) << 4));
-            const u32x4 b = *reinterpret_cast<const u32x4*>(halo + h1 * 128 + ((chunk ^ (h1 & 7)) << 4));
-            res[it] = blend2<T>(a, b, 1.f - wx, wx);
-            if (!ok) res[it] = u32x4{0u, 0u, 0u, 0u};
+        for (int g0 = 0; g0 < HALO_ITERS; g0 += G) {
+            u32x4 q[G][4];
+            float wy1[G], wx1[G];
+            bool okg[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g0 + g >= HALO_ITERS) break;
+                const int piece = (g0 + g) * 256 + t_id;
+                const int hp = piece >> 3, chunk = (piece & 7) ^ (hp & 7);
+                const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+                const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+                okg[g] = hp < HALO_PX && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
+                // pieces outside the image (written as zeros) read inside the parked patch all the same
+                const float fy = up_sy * (float)min(max(iy, iy_lo), iy_hi), fx = up_sx * (float)min(max(ix, ix_lo), ix_hi);
+                const int y0 = (int)fy, x0 = (int)fx;
+                wy1[g] = fy - (float)y0;
+                wx1[g] = fx - (float)x0;
+                const int r0 = (y0 - ys0) * 32, r1 = (min(y0 + 1, src_h - 1) - ys0) * 32;
+                const int c0 = x0 - xs0, c1 = min(x0 + 1, src_w - 1) - xs0;
+                const int s0 = (chunk ^ (c0 & 7)) << 4, s1 = (chunk ^ (c1 & 7)) << 4;
+                q[g][0] = *reinterpret_cast<const u32x4*>(halo + (r0 + c0) * 128 + s0);
+                q[g][1] = *reinterpret_cast<const u32x4*>(halo + (r0 + c1) * 128 + s1);
+                q[g][2] = *reinterpret_cast<const u32x4*>(halo + (r1 + c0) * 128 + s0);
+                q[g][3] = *reinterpret_cast<const u32x4*>(halo + (r1 + c1) * 128 + s1);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g0 + g >= HALO_ITERS) break;
+                const float w00 = (1.f - wy1[g]) * (1.f - wx1[g]), w01 = (1.f - wy1[g]) * wx1[g];
+                const float w10 = wy1[g] * (1.f - wx1[g]), w11 = wy1[g] * wx1[g];
+                res[g0 + g] = blend4<T>(q[g], w00, w01, w10, w11);
+                if (!okg[g]) res[g0 + g] = u32x4{0u, 0u, 0u, 0u};
+            }
+            __builtin_amdgcn_sched_barrier(0);               // keep the groups apart: only G x 4 reads are live at a time
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                                 // every parked value has been read
@@ -294,7 +301,11 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     for (int s = 0; s < steps; ++s) {
         const int cc = s / SPC, tg = s - cc * SPC;
         if (tg == 0) {                                       // all reads of the previous slice ended at the last barrier
-            if (UP) { if (two_pass) blend_halo_2pass(cc); else blend_halo(cc); } else issue_halo(cc);
+            if (UP) {
+                if (parked) blend_halo_parked(cc); else blend_halo(cc);
+            } else {
+                issue_halo(cc);
+            }
         }
         if (s + 1 < steps) {
             issue_w(s + 1, (s + 1) & 1);
@@ -404,12 +415,13 @@ int launch_cfg(const VdaGemmArgs& a, hipStream_t s) {
     const int tiles_x = (a.out_w + PT_W - 1) / PT_W, tiles_y = (a.out_h + PT_H - 1) / PT_H;
     const int imgs = a.M / (a.out_h * a.out_w);
     const int lds = HALO_BYTES + 2 * TPS * TN * 16 * 128;
-    // the separable resampling needs the 34 halo columns to come from at most 32 source columns; its second rounding is
-    // 2^-12 relative in fp16 but 2^-9 in bf16, where the four-tap form is kept
-    const int two_pass = UP && sizeof(T) == 2 && a.ab_type == VDA_T_F16 && 10L * (a.up_w - 1) <= 9L * (a.in_w - 1);
+    // The parked form of the resampling needs a patch's halo to come from at most 32 source columns and 11 source rows:
+    // horizontal scale <= 0.9, vertical <= 1.  fp16 maps only: the bf16 blend converts every value and needs the registers
+    // that form leaves to the four-tap loader.
+    const int parked = UP && a.ab_type == VDA_T_F16 && 10L * (a.up_w - 1) <= 9L * (a.in_w - 1) && a.up_h <= a.in_h;
     auto k = conv3_direct_kernel<TN, TPS, RELU_IN, UP, SPEC, T>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)(imgs * tiles_x * tiles_y), a.N / (TN * 16)), dim3(256), lds, s, a, tiles_x, tiles_y, two_pass);
+    hipLaunchKernelGGL(k, dim3((unsigned)(imgs * tiles_x * tiles_y), a.N / (TN * 16)), dim3(256), lds, s, a, tiles_x, tiles_y, parked);
     return hip_rc(hipGetLastError());
 }
 

@@ -251,8 +251,8 @@ def test_conv3x3_direct_kernel_residual_unit(B, h, w_, C):
     (2, 9, 9, 33, 65, 64, 64, "plain"),           # 64 output channels, one channel slice, large ratios
     (1, 12, 40, 12, 80, 192, 256, "plain"),       # one axis unchanged; two 128-channel workgroup columns; three slices
     (1, 1, 1, 5, 7, 64, 32, "relu_in"),           # single source pixel: every sample is that pixel
-    (1, 8, 70, 17, 72, 64, 32, "plain"),          # width ratio above 0.9: the four-tap loader instead of the separable one
-    (1, 20, 50, 21, 100, 128, 128, "plain"),      # height ratio near 1 with the separable loader
+    (1, 8, 70, 17, 72, 64, 32, "plain"),          # width ratio above 0.9: the four-tap loader from global memory instead of the parked source patch
+    (1, 20, 50, 21, 100, 128, 128, "plain"),      # height ratio near 1 with the parked source patch (11 source rows)
 ])
 def test_conv3x3_direct_kernel_with_fused_bilinear_input(B, sh, sw, h, w_, cin, cout, mode, dt):
     """conv3x3(bilinear(x, align_corners=True)) with the resampling done inside the convolution's patch loader
