@@ -95,6 +95,10 @@ typedef struct VdaGemmArgs {
                              Only where the direct 3x3 kernel applies (see tile_cfg 3), else VDA_ESHAPE              */
     float acc_scale;      /* 0 or 1: off.  Otherwise every sum acc[m][n] is multiplied by it before the epilogue: the
                              inverse of the powers of two that a and w were scaled by before rounding (see vda_split3) */
+    int cin_used;         /* CONV3 only; 0 = cin.  Otherwise a multiple of 32 <= cin: only channels 0 .. cin_used-1 of every
+                             pixel enter the products (the rest of the cin-wide pixel, e.g. the padding of a 32-channel map
+                             stored 64 wide, is neither multiplied nor required to hold numbers).  Only where the direct
+                             3x3 kernel applies (see tile_cfg 3), else VDA_ESHAPE                                      */
 } VdaGemmArgs;
 
 int vda_gemm(const VdaGemmArgs* args, void* stream);

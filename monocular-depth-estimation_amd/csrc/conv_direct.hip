@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     // row of 32 pixels x 8 chunks per instruction -- a third of the loads of the four-tap form, no registers, ONE round of
     // memory latency however few registers the accumulators leave -- and every halo piece is then blended from four LDS
     // reads with the four-tap form's arithmetic (one rounding).  In place: all pieces are formed before any is written.
-    auto blend_halo_parked = [&](int cc) {
+    auto blend_halo_parked = [&](int cc, bool half) {
         const unsigned px_step = p.cin * sizeof(T), row_step = src_w * px_step;
         const char* a_cc = reinterpret_cast<const char*>(a_img) + cc * 128;
         const int iy_lo = max(oy0 - 1, 0), iy_hi = min(oy0 + PT_H, p.in_h - 1);
@@ -224,6 +224,8 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (also the weights of this step, needed next anyway)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        // A half slice (only 32 of the slice's 64 channels are used) has four pieces per halo pixel instead of eight.
+        const int sh = half ? 2 : 3, iters = half ? (HALO_PX * 4 + 255) / 256 : HALO_ITERS;
         u32x4 res[HALO_ITERS];
         constexpr int G = TN >= 8 ? 2 : 4;                   // pieces whose four reads each are in flight together (registers)
         // The positions and weights below do not depend on the channel slice.  Left alone the compiler computes them once,
@@ -237,9 +239,9 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
             bool okg[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if (g0 + g >= HALO_ITERS) break;
+                if (g0 + g >= iters) break;
                 const int piece = (g0 + g) * 256 + t_id;
-                const int hp = piece >> 3, chunk = (piece & 7) ^ (hp & 7);
+                const int hp = piece >> sh, lo = piece & ((1 << sh) - 1), chunk = half ? lo : lo ^ (hp & 7);
                 const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
                 const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
                 okg[g] = hp < HALO_PX && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if (g0 + g >= HALO_ITERS) break;
+                if (g0 + g >= iters) break;
                 const float w00 = (1.f - wy1[g]) * (1.f - wx1[g]), w01 = (1.f - wy1[g]) * wx1[g];
                 const float w10 = wy1[g] * (1.f - wx1[g]), w11 = wy1[g] * wx1[g];
                 res[g0 + g] = blend4<T>(q[g], w00, w01, w10, w11);
@@ -270,7 +272,12 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
         __builtin_amdgcn_s_barrier();                                                 // every parked value has been read
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int it = 0; it < HALO_ITERS; ++it) *reinterpret_cast<u32x4*>(halo + (it * 256 + tid) * 16) = res[it];
+        for (int it = 0; it < HALO_ITERS; ++it) {
+            if (it >= iters) break;
+            const int piece = it * 256 + t_id;
+            const int hp = piece >> sh, lo = piece & ((1 << sh) - 1), chunk = half ? lo : lo ^ (hp & 7);
+            if (hp < HALO_PX) *reinterpret_cast<u32x4*>(halo + hp * 128 + ((chunk ^ (hp & 7)) << 4)) = res[it];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     auto issue_w = [&](int s, int buf) {
@@ -296,13 +303,19 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int steps = (p.cin / 64) * SPC;
+    // cin_used: the last slice may be a half slice (32 channels): its second K step and, in the parked resampling, the
+    // pieces of its upper 32 channels are skipped
+    const int cin_eff = pa.cin_used > 0 ? pa.cin_used : p.cin;
+    const int slices = (cin_eff + 63) / 64;
+    const bool tail_half = (cin_eff & 63) == 32;
+    const int steps = slices * SPC;
     issue_w(0, 0);
     for (int s = 0; s < steps; ++s) {
         const int cc = s / SPC, tg = s - cc * SPC;
+        const bool half = tail_half && cc == slices - 1;
         if (tg == 0) {                                       // all reads of the previous slice ended at the last barrier
             if (UP) {
-                if (parked) blend_halo_parked(cc); else blend_halo(cc);
+                if (parked) blend_halo_parked(cc, half); else blend_halo(cc);
             } else {
                 issue_halo(cc);
             }
@@ -325,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
             const int toff = dy * HALO_W + dx;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 1 && half) continue;
                 frag_t wf[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const frag_t*>(wb + t_in * N * 128 + w_off[j][ks]);

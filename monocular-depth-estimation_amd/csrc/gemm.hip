@@ -187,8 +187,9 @@ int check_args(const VdaGemmArgs* args) {
         if (a.stride < 1 || a.out_h <= 0 || a.out_w <= 0 || a.M % (a.out_h * a.out_w) != 0) return VDA_ESHAPE;
         if (a.out_h != (a.in_h - 1) / a.stride + 1 || a.out_w != (a.in_w - 1) / a.stride + 1) return VDA_ESHAPE;
         if (a.up_h < 0 || a.up_w < 0 || (a.up_h > 0) != (a.up_w > 0)) return VDA_EINVAL;
+        if (a.cin_used < 0 || a.cin_used % 32 != 0 || a.cin_used > a.cin) return VDA_ESHAPE;
     } else if (a.a_mode == VDA_A_LINEAR) {
-        if (a.lda < a.K || a.lda % 8 != 0 || a.up_h != 0 || a.up_w != 0) return VDA_ESHAPE;
+        if (a.lda < a.K || a.lda % 8 != 0 || a.up_h != 0 || a.up_w != 0 || a.cin_used != 0) return VDA_ESHAPE;
     } else {
         return VDA_EINVAL;
     }
@@ -216,7 +217,8 @@ int choose_kernel(const VdaGemmArgs& a) {
     // 3x3 convolutions: the direct kernel copies each input pixel once per patch and channel slice instead of once per tap.
     // Narrow outputs (N <= 128) always gain (1.3x at N = 128, 1.8x at N = 32); wide ones only while the 8 x 32 patches
     // cover the image well (148 x 148: 90 % covered, +10 %; 74 x 74: 71 %, -4 % against the 256x256 tile).
-    if (a.a_mode == VDA_A_CONV3 && a.up_h > 0)       // fused upsampling exists in the direct kernel only
+    // fused upsampling and partly used pixels exist in the direct kernel only
+    if (a.a_mode == VDA_A_CONV3 && (a.up_h > 0 || (a.cin_used != 0 && a.cin_used != a.cin)))
         return ((a.tile_cfg == 0 || a.tile_cfg == 3) && conv_direct_supports(a)) ? VDA_KERNEL_CONV_DIRECT : VDA_ESHAPE;
     if ((a.tile_cfg == 0 || a.tile_cfg == 3) && conv_direct_supports(a)) {
         const long ty = (a.out_h + 7) / 8, tx = (a.out_w + 31) / 32;

@@ -288,14 +288,19 @@ class Engine:
         # From here on every stage works frame by frame (two fusion blocks, the output convolutions): two halves of the
         # frames on the two streams, as in the encoder.
         depth = _empty((frames, 14 * hp, 14 * wp), torch.float32, dev)
+        narrow = not self.split and w.F2 < w.F2p and w.F2 % 32 == 0
 
         def tail(f0, f1):
             p2 = self.fusion(2, p3[f0:f1], r2[f0:f1], 4 * hp, 4 * wp)
             # the two largest resamplings (to 8x and 14x the patch grid) are folded into the convolutions that read them
             p1 = self.fusion(1, p2, r1[f0:f1], 8 * hp, 8 * wp, resize=False)
-            o1 = self.conv3(p1, w.oc1_w, w.oc1_b, w.F2p, resized=(8 * hp, 8 * wp))
+            if narrow:      # ViT-S: 32 channels in a map stored 64 wide; the padding is neither computed nor read
+                o1 = _empty((f1 - f0, 8 * hp, 8 * wp, w.F2p), self.hdt, dev)
+                self.conv3(p1, w.oc1_w[:w.F2], w.oc1_b[:w.F2], w.F2, out=o1, ldc=w.F2p, resized=(8 * hp, 8 * wp))
+            else:
+                o1 = self.conv3(p1, w.oc1_w, w.oc1_b, w.F2p, resized=(8 * hp, 8 * wp))
             self.conv3(o1, w.oc2_w, w.oc2_b, 32, out=depth[f0:f1], ldc=4, epi=hip.EPI_DOT, dot_w=w.dot_w, dot_b=w.dot_b,
-                       resized=(14 * hp, 14 * wp))
+                       resized=(14 * hp, 14 * wp), **(dict(cin_used=w.F2) if narrow else {}))
 
         if joined is not None and frames > 1:
             main, side = torch.cuda.current_stream(), self.side_streams[0]

@@ -36,7 +36,7 @@ class GemmArgs(C.Structure):
         ("ab_type", C.c_int), ("relu_in", C.c_int),
         ("in_h", C.c_int), ("in_w", C.c_int), ("cin", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int), ("stride", C.c_int),
         ("ct_h", C.c_int), ("ct_w", C.c_int), ("ct_k", C.c_int), ("ct_c", C.c_int), ("tile_cfg", C.c_int),
-        ("up_h", C.c_int), ("up_w", C.c_int), ("acc_scale", C.c_float),
+        ("up_h", C.c_int), ("up_w", C.c_int), ("acc_scale", C.c_float), ("cin_used", C.c_int),
     ]
 
 
@@ -125,10 +125,11 @@ def zero_page(device):
 
 def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr=0, resid2=None, ldr2=0, act=ACT_NONE,
          epi=EPI_PLAIN, relu_in=False, conv=None, convt=None, dot_w=None, dot_b=0.0, tile_cfg=None, upsample_from=None,
-         acc_scale=1.0):
+         acc_scale=1.0, cin_used=0):
     """Enqueue one vda_gemm.  ``conv`` = (in_h, in_w, cin, out_h, out_w, stride); ``convt`` = (h, w, k, c);
     ``upsample_from`` = (h, w) of the map ``a`` that is bilinearly resampled to in_h x in_w on the fly;
-    ``acc_scale`` multiplies every sum before the epilogue (operands pre-scaled by powers of two)."""
+    ``acc_scale`` multiplies every sum before the epilogue (operands pre-scaled by powers of two); ``cin_used``: only the
+    first so many channels of every input pixel are multiplied (direct 3x3 kernel only)."""
     _dev(a, w, out, bias, gamma, resid, resid2, dot_w)
     g = GemmArgs()
     g.a, g.w, g.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -141,6 +142,7 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
     g.M, g.N, g.K, g.lda, g.ldc, g.ldr, g.ldr2 = M, N, K, lda, ldc, ldr, ldr2
     g.act, g.epi, g.relu_in = act, epi, int(bool(relu_in))
     g.acc_scale = float(acc_scale)
+    g.cin_used = int(cin_used)
     g.tile_cfg = TILE_CFG if tile_cfg is None else tile_cfg
     if a.dtype != w.dtype:
         raise TypeError("vda_gemm: a and w must share one 16-bit type")

@@ -115,7 +115,7 @@ class PackedWeights:
         self.F = features
         self.oc = list(out_channels)
         self.Fp = pad64(features)
-        self.F2p = pad64(features // 2)
+        self.F2, self.F2p = features // 2, pad64(features // 2)
         self.ocp = [pad64(c) for c in self.oc]
         self._pos_cache = {}
         g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32)  # noqa: E731

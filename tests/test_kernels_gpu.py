@@ -290,6 +290,50 @@ def test_conv3x3_direct_kernel_with_fused_bilinear_input(B, sh, sw, h, w_, cin, 
     close(fused, two, tol, "fused vs bilinear kernel + direct convolution")
 
 
+@pytest.mark.parametrize("dt", [torch.float16, BF])
+@pytest.mark.parametrize("B,sh,sw,h,w_,cin,used,cout,mode", [
+    (2, 11, 19, 21, 37, 64, 32, 32, "dot"),        # the ViT-S output tail: a 32-channel map stored 64 wide, resampled, 1x1 tail
+    (1, 9, 30, 17, 60, 128, 96, 64, "plain"),      # one and a half slices
+    (2, 14, 35, 14, 35, 64, 32, 32, "same"),       # no resampling: the plain halo copy with a half slice
+    (1, 8, 70, 17, 72, 64, 32, 32, "plain"),       # width ratio above 0.9: four-tap loader from global memory, half slice
+])
+def test_conv3x3_direct_kernel_uses_only_the_first_channels_of_a_pixel(B, sh, sw, h, w_, cin, used, cout, mode, dt):
+    """cin_used: channels from `used` on are not multiplied and need not hold numbers (they are NaN here, and so are the
+    weights that would meet them)."""
+    x = rnd((B, sh, sw, cin), 1, 1.0, dt)
+    wt = rnd((cout, cin, 3, 3), 2, 1 / math.sqrt(9 * used), dt)
+    bias = rnd((cout,), 3, 0.1, torch.float32)
+    xs = x[..., :used].float().permute(0, 3, 1, 2)
+    if mode != "same":
+        xs = F.interpolate(xs, size=(h, w_), mode="bilinear", align_corners=True)
+        xs = xs.to(dt).float()                             # the fused patch is rounded to the storage type
+    want = F.conv2d(xs, wt[:, :used].float(), bias, padding=1)
+    x[..., used:] = float("nan")
+    wt[:, used:] = float("nan")
+    wg = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
+    kw = dict(M=B * h * w_, N=cout, K=9 * cin, lda=0, bias=bias, conv=(h, w_, cin, h, w_, 1), cin_used=used)
+    if mode != "same":
+        kw["upsample_from"] = (sh, sw)
+    if mode == "dot":
+        dw, db = rnd((32,), 4, 0.3, torch.float32), 0.05
+        want = F.relu((F.relu(want) * dw.view(1, -1, 1, 1)).sum(1) + db)
+        out = torch.full((B, h, w_), float("nan"), dtype=torch.float32, device=DEV)
+        hip.gemm(x, wg, out, ldc=4, epi=hip.EPI_DOT, dot_w=dw, dot_b=db, **kw)
+        close(out, want, 4e-3 if dt == BF else 2e-3, "half slice, dot tail")
+    else:
+        out = torch.full((B, h, w_, cout), float("nan"), dtype=dt, device=DEV)
+        hip.gemm(x, wg, out, ldc=cout, **kw)
+        close(out, want.permute(0, 2, 3, 1), BF_OUT, "half slice")
+    # not a multiple of 32, more than cin, or a kernel that cannot skip channels: refused
+    scratch = torch.empty((B, h, w_, cout), dtype=dt, device=DEV)
+    for bad in (24, cin + 32):
+        with pytest.raises(RuntimeError):
+            hip.gemm(x, wg, scratch, ldc=cout, **{**kw, "cin_used": bad})
+    wg48 = rnd((48, 9 * cin), 5, 0.1, dt)
+    with pytest.raises(RuntimeError):                                   # 48 output channels: implicit GEMM, which reads whole pixels
+        hip.gemm(x, wg48, torch.empty((B, h, w_, 48), dtype=dt, device=DEV), ldc=48, **{**kw, "N": 48, "bias": None})
+
+
 def test_fused_bilinear_input_is_refused_where_the_direct_kernel_does_not_apply():
     x = rnd((1, 5, 5, 64), 1, 1.0, torch.float16)
     wg = rnd((48, 9 * 64), 2, 0.1, torch.float16)
