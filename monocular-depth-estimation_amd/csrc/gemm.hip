@@ -91,6 +91,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const VdaGemmArgs p,
 
     const int nk = p.K / BK;
     const int frow = lane & 15, fq = lane >> 4;
+    // bias + fp32 residual into an fp32 output (the encoder's proj / fc2 at widths the 256x256 kernel does not take): fetch
+    // the residual now; it lands during the K loop
+    constexpr bool PRE = SPEC == EPI_SPEC_F32_RES32 && TM * TN <= 16;
+    f32x4 pre[PRE ? TM : 1][TN];
+    if constexpr (PRE) residual_prefetch<TM, TN>(p, pre, m0 + wm * (BM / WM) + frow, n0 + wn * (BN / WN) + fq * 4);
     stage(0, 0);
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) lgkmcnt(0)
     __syncthreads();
@@ -125,7 +130,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const VdaGemmArgs p,
         __syncthreads();   // also drains the in-flight copy of step kt+1 (vmcnt(0) precedes the barrier)
     }
 
-    gemm_epilogue_spec<SPEC, T, TM, TN>(p, acc, m0 + wm * (BM / WM) + frow, n0 + wn * (BN / WN) + fq * 4, fq, smem + wave * STAGE_BYTES);
+    gemm_epilogue_spec<SPEC, T, TM, TN>(p, acc, m0 + wm * (BM / WM) + frow, n0 + wn * (BN / WN) + fq * 4, fq, smem + wave * STAGE_BYTES,
+                                        PRE ? pre : nullptr);
 }
 
 namespace {

@@ -77,7 +77,7 @@ constexpr int STAGE_BYTES = 16 * (4 * 16 * 4 + 16);     // 16 rows x (up to 64 f
 
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq,
-                                                     char* stage) {
+                                                     char* stage, const f32x4 (*pre)[TN] = nullptr) {
     const int lane = threadIdx.x & 63, frow = lane & 15;
     const int esz = p.out_type == VDA_T_F32 ? 4 : 2;
     const bool geglu = p.epi == VDA_EPI_GEGLU;
@@ -136,7 +136,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                 }
                 v *= gam[j];
-                if (m < p.M && n < p.N) {
+                if (pre) {                                  // the residual was fetched before the K loop (see residual_prefetch)
+                    v += pre[i][j];
+                } else if (m < p.M && n < p.N) {
                     if (p.resid_type != VDA_T_NONE) v += load4(p.resid, p.resid_type, (size_t)m * p.ldr + n);
                     if (p.resid2) v += load4(p.resid2, p.resid_type, (size_t)m * p.ldr2 + n);
                 }
@@ -169,7 +171,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
 
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq,
-                                              char* stage = nullptr) {
+                                              char* stage = nullptr, const f32x4 (*pre)[TN] = nullptr) {
     if (stage && (p.epi == VDA_EPI_PLAIN || p.epi == VDA_EPI_GEGLU || p.epi == VDA_EPI_CONVT)) {
         const int esz = p.out_type == VDA_T_F32 ? 4 : 2;
         const int n_out = p.epi == VDA_EPI_GEGLU ? p.N / 2 : p.N;
@@ -178,7 +180,7 @@ __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)
         // for the transposed convolution a block must not straddle two kernel taps
         if ((p.ldc * esz) % 16 == 0 && (n_out * esz) % 16 == 0 && (cols * esz) % 16 == 0 && (cols * esz) <= 256 &&
             ((uintptr_t)p.out & 15) == 0 && (p.epi != VDA_EPI_CONVT || p.ct_c % cols == 0)) {
-            gemm_epilogue_staged<TM, TN>(p, acc, mrow0, ncol0, fq, stage);
+            gemm_epilogue_staged<TM, TN>(p, acc, mrow0, ncol0, fq, stage, pre);
             return;
         }
     }
@@ -263,8 +265,12 @@ __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             v *= g;
-            if (p.resid_type != VDA_T_NONE) v += load4(p.resid, p.resid_type, (size_t)m * p.ldr + n);
-            if (p.resid2) v += load4(p.resid2, p.resid_type, (size_t)m * p.ldr2 + n);
+            if (pre) {
+                v += pre[i][j];
+            } else {
+                if (p.resid_type != VDA_T_NONE) v += load4(p.resid, p.resid_type, (size_t)m * p.ldr + n);
+                if (p.resid2) v += load4(p.resid2, p.resid_type, (size_t)m * p.ldr2 + n);
+            }
             size_t idx;
             if (p.epi == VDA_EPI_CONVT) {
                 const int iy = m / p.ct_w, x = m - iy * p.ct_w;     // iy = img * ct_h + y
@@ -348,10 +354,27 @@ __device__ __forceinline__ void scale_acc(const VdaGemmArgs& p, f32x4 (&acc)[TM]
 }
 
 template <int SPEC, typename T, int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue_spec(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq, char* stage) {
+__device__ __forceinline__ void gemm_epilogue_spec(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq, char* stage,
+                                                   const f32x4 (*pre)[TN] = nullptr) {
     scale_acc<TM, TN>(p, acc);
     const VdaGemmArgs q = epi_spec_args<SPEC, T>(p);
-    gemm_epilogue<TM, TN>(q, acc, mrow0, ncol0, fq, stage);
+    gemm_epilogue<TM, TN>(q, acc, mrow0, ncol0, fq, stage, pre);
+}
+
+// The fp32 residual of a wave's block (this lane's four columns of each 16x16 tile), fetched into registers BEFORE the K
+// loop of a kernel whose accumulators leave the room: the epilogue otherwise fetches it one 16-row block at a time, each
+// fetch a full memory latency that nothing overlaps.  Elements outside M x N are zero.  (The residual may alias the output:
+// every element is read and later written by the same lane.)
+template <int TM, int TN>
+__device__ __forceinline__ void residual_prefetch(const VdaGemmArgs& p, f32x4 (&pre)[TM][TN], int mrow0, int ncol0) {
+    const float* r = reinterpret_cast<const float*>(p.resid);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int m = mrow0 + i * 16, n = ncol0 + j * 16;
+            pre[i][j] = (m < p.M && n < p.N) ? *reinterpret_cast<const f32x4*>(r + (size_t)m * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 }
 
 // 256x256-tile kernel with the 4-phase software pipeline (gemm256.hip)
