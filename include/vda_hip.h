@@ -99,6 +99,23 @@ typedef struct VdaGemmArgs {
                              pixel enter the products (the rest of the cin-wide pixel, e.g. the padding of a 32-channel map
                              stored 64 wide, is neither multiplied nor required to hold numbers).  Only where the direct
                              3x3 kernel applies (see tile_cfg 3), else VDA_ESHAPE                                      */
+    /* LayerNorm folded into the two products around it (block.py:84,87: norm1 -> attention.py:51 qkv, norm2 -> mlp.py:36
+       fc1).  With W' = W diag(ln_weight) rounded to the operand type and colsum[n] = sum_k W'[n][k]:
+           LN(x) W^T + b = rstd (x W'^T - mean colsum) + (b + W ln_bias),
+       so the product can read the un-normalised rows, rounded to 16 bits once, and normalise its sums.
+       Producer side (the product that writes the rows x, i.e. proj / fc2 with their residual): */
+    void*  out16;         /* NULL = off.  Otherwise ab_type [M][ld16]: every output value rounded to the operand type, stored
+                             beside the fp32 output.  Needs out_type F32, EPI_PLAIN, A_LINEAR, N % 64 == 0, N >= 128,
+                             16-byte aligned out rows and 8-byte aligned out16 rows, and row_part                      */
+    float* row_part;      /* [M][N/64][2]: for every row and every block of 64 columns the sum and the sum of squares of
+                             the ROUNDED values, added in an order that does not depend on where the row lies in a tile
+                             (vda_rowstats_finish turns them into mean and 1/std)                                      */
+    int    ld16;
+    /* Consumer side (qkv / fc1 reading the rounded rows as A): */
+    const float* row_stat;  /* NULL = off.  Otherwise [M][2] = (mean, 1/sqrt(var + eps)) of each row of A; every sum becomes
+                               rstd[m] * (acc[m][n] - mean[m] * w_colsum[n]) before bias / activation.  A_LINEAR, EPI_PLAIN,
+                               no residual                                                                              */
+    const float* w_colsum;  /* [N], required with row_stat                                                            */
 } VdaGemmArgs;
 
 int vda_gemm(const VdaGemmArgs* args, void* stream);
@@ -132,6 +149,17 @@ int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, 
 int vda_layernorm(const float* x, void* out, const float* weight, const float* bias, int rows, int C, float eps,
                   int rows_per_group, int in_group, int in_skip, const float* pe, int pe_hw, int pe_T, int out_type,
                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Row statistics for a LayerNorm that is folded into the product that follows it (VdaGemmArgs.row_stat; block.py:84,87).
+ * vda_round_rowstats: fp32 rows [rows][C] -> out16 [rows][C] (out_type BF16 or F16: the rows rounded once) and
+ *   stat[rows][2] = (mean, 1/sqrt(var + eps)) of the ROUNDED values (biased variance): the first LayerNorm of the
+ *   encoder, whose input no product of this library wrote.  C % 4 == 0, C <= 2048.
+ * vda_rowstats_finish: part[rows][slots][2] (sum, sum of squares per 64-column block, as VdaGemmArgs.row_part writes them)
+ *   -> stat[rows][2]; C = 64 * slots values per row.
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_round_rowstats(const float* x, void* out16, float* stat, int rows, int C, float eps, int out_type, void* stream);
+int vda_rowstats_finish(const float* part, float* stat, int rows, int slots, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GroupNorm over NHWC maps (dtype BF16, F16 or F32): statistics per (frame, group) over hw * C/groups values, affine,

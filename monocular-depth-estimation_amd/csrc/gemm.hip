@@ -93,7 +93,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const VdaGemmArgs p,
     const int frow = lane & 15, fq = lane >> 4;
     // bias + fp32 residual into an fp32 output (the encoder's proj / fc2 at widths the 256x256 kernel does not take): fetch
     // the residual now; it lands during the K loop
-    constexpr bool PRE = SPEC == EPI_SPEC_F32_RES32 && TM * TN <= 16;
+    constexpr bool PRE = (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_F32_RES32_EMIT) && TM * TN <= 16;
     f32x4 pre[PRE ? TM : 1][TN];
     if constexpr (PRE) residual_prefetch<TM, TN>(p, pre, m0 + wm * (BM / WM) + frow, n0 + wn * (BN / WN) + fq * 4);
     stage(0, 0);
@@ -130,6 +130,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const VdaGemmArgs p,
         __syncthreads();   // also drains the in-flight copy of step kt+1 (vmcnt(0) precedes the barrier)
     }
 
+    // (The row statistics of a folded LayerNorm are loaded by the epilogue itself here, one m-tile at a time.  Fetched ahead
+    // of the K loop, as the 256x256 kernel does, this kernel produced wrong 16-row blocks whenever another stream's kernels
+    // shared the chip: not understood, reproducible, and gone with the loads moved here.)
     gemm_epilogue_spec<SPEC, T, TM, TN>(p, acc, m0 + wm * (BM / WM) + frow, n0 + wn * (BN / WN) + fq * 4, fq, smem + wave * STAGE_BYTES,
                                         PRE ? pre : nullptr);
 }
@@ -163,6 +166,7 @@ int launch_t(const VdaGemmArgs& a, hipStream_t s) {
         VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_GELU) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_F32_RES32)
         VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_RES) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_RES32) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_GEGLU)
         VDA_CASE(VDA_A_LINEAR, EPI_SPEC_F32) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_CONVT)
+        VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_LN) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_GELU_LN) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_F32_RES32_EMIT)
         default: return launch_k<BM, BN, WM, WN, VDA_A_LINEAR, EPI_SPEC_GENERAL, T>(a, s);
     }
 #undef VDA_CASE
@@ -214,6 +218,21 @@ int check_args(const VdaGemmArgs* args) {
     if ((a.act == VDA_ACT_GELU || a.epi == VDA_EPI_GEGLU) && a.out_type == VDA_T_F32) return VDA_ESHAPE;
     if (a.ab_type != VDA_T_BF16 && a.ab_type != VDA_T_F16) return VDA_EINVAL;
     if (a.tile_cfg < 0 || a.tile_cfg > 3) return VDA_EINVAL;
+    // folded LayerNorm: consumer side (row_stat / w_colsum) and producer side (out16 / row_part)
+    if ((a.row_stat != nullptr) != (a.w_colsum != nullptr)) return VDA_EINVAL;
+    if (a.row_stat) {
+        if (a.a_mode != VDA_A_LINEAR || a.epi != VDA_EPI_PLAIN || a.resid_type != VDA_T_NONE || a.gamma) return VDA_ESHAPE;
+        if (((uintptr_t)a.row_stat & 7) != 0 || ((uintptr_t)a.w_colsum & 15) != 0) return VDA_ESHAPE;
+    }
+    if ((a.out16 != nullptr) != (a.row_part != nullptr)) return VDA_EINVAL;
+    if (a.out16) {
+        if (a.a_mode != VDA_A_LINEAR || a.epi != VDA_EPI_PLAIN || a.out_type != VDA_T_F32 || a.gamma) return VDA_ESHAPE;
+        if (a.N % 64 != 0 || a.N < 128 || a.ld16 < a.N || a.ld16 % 4 != 0) return VDA_ESHAPE;
+        if (((uintptr_t)a.out & 15) != 0 || ((uintptr_t)a.out16 & 7) != 0 || ((uintptr_t)a.row_part & 7) != 0) return VDA_ESHAPE;
+        if (a.tile_cfg == 3) return VDA_ESHAPE;
+        // the kernels address both arrays with 32-bit byte offsets
+        if ((uint64_t)a.M * a.ld16 * 2 >= (1ull << 32) || (uint64_t)a.M * (a.N / 64) * 8 >= (1ull << 32)) return VDA_ESHAPE;
+    }
     return VDA_OK;
 }
 

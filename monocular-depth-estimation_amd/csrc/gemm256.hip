@@ -37,6 +37,8 @@ constexpr int R_A0 = 0, R_B0 = 1, R_B1 = 2, R_A1 = 3;
 
 __device__ __forceinline__ void wait_vm8() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void phase_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -55,15 +57,31 @@ __device__ __forceinline__ void phase_barrier() {
 // Vector-memory operations complete in order, stores included, so the wait before m-tile i counts what was issued after
 // its DMA: with D = the 4 DMA pieces and S = the 4 stores of an m-tile the issue order is D0 D1 D2 D3 S0 D4 S1 D5 S2 D6 S3
 // D7 S4 S5 S6 S7.  Every store below is issued by every wave (no bounds test), or those counts would not hold.
+//
+// EMIT (the producer side of a folded LayerNorm, VdaGemmArgs.out16 / row_part): each 16-byte piece a lane copies out is also
+// rounded to the operand type and stored (the 16 lanes of a DPP row cover a row's 64 columns: one 128-byte line), and the
+// row's sums over the block are reduced across those lanes; with the 8-byte store of the rounded piece and the 8-byte store
+// of the sums (lane c == 0 of every DPP row: never an empty instruction) an m-tile then issues S = 12 stores instead of 4.
+template <bool EMIT, typename T>
 __device__ __forceinline__ void epilogue_res32_dma(const VdaGemmArgs& p, f32x4 (&acc)[8][4], int m_wave0, int n_wave0, char* slots) {
     const int lane = threadIdx.x & 63, frow = lane & 15, fq = lane >> 4;
     const int c = lane & 15, rr = lane >> 4;
-    const float* resid = reinterpret_cast<const float*>(p.resid);
-    float* out = reinterpret_cast<float*>(p.out);
     f32x4 bias[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         bias[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n_wave0 + j * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* resid = reinterpret_cast<const float*>(p.resid);
+    float* out = reinterpret_cast<float*>(p.out);
+    // producer-side fields of the folded LayerNorm, fetched from the kernel arguments here (see kernarg_field_now)
+    void* out16 = nullptr;
+    float* row_part = nullptr;
+    unsigned ld16 = 0;
+    if (EMIT) {
+        out16 = kernarg_field_now<void*>(offsetof(VdaGemmArgs, out16));
+        row_part = kernarg_field_now<float*>(offsetof(VdaGemmArgs, row_part));
+        ld16 = (unsigned)kernarg_field_now<int>(offsetof(VdaGemmArgs, ld16));
+    }
+    const unsigned slots_n = (unsigned)(p.N >> 6);
     auto issue = [&](int i) {
         char* slot = slots + (i & 3) * 4096;
 #pragma unroll
@@ -85,18 +103,26 @@ __device__ __forceinline__ void epilogue_res32_dma(const VdaGemmArgs& p, f32x4 (
             const int r = q * 4 + rr;
             const u32x4 v = *reinterpret_cast<const u32x4*>(slot + r * 256 + (c << 4));
             *reinterpret_cast<u32x4*>(out + (size_t)(m_wave0 + i * 16 + r) * p.ldc + n_wave0 + ((c ^ r) << 2)) = v;
+            if (EMIT) {
+                const unsigned m = (unsigned)(m_wave0 + i * 16 + r);
+                emit_rounded_row<T>(out16, row_part, __builtin_bit_cast(f32x4, v), (m * ld16 + (unsigned)(n_wave0 + ((c ^ r) << 2))) * 2u,
+                                    (m * slots_n + (unsigned)(n_wave0 >> 6)) * 8u, true, c == 0);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot has been read before a DMA refills it
     };
+    // before m-tile i everything issued after its DMA may still be in flight: D = 4 per later DMA, S per earlier m-tile's stores
+    constexpr int S = EMIT ? 12 : 4;
     issue(0); issue(1); issue(2); issue(3);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); tile(0); issue(4);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); tile(1); issue(5);
-    asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); tile(2); issue(6);
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); tile(3); issue(7);
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); tile(4);
-    asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); tile(5);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); tile(6);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); tile(7);
+    wait_vm<12>(); tile(0); issue(4);                  // D1 D2 D3
+    wait_vm<12 + S>(); tile(1); issue(5);              // D2 D3 S0 D4
+    wait_vm<12 + 2 * S>(); tile(2); issue(6);          // D3 S0 D4 S1 D5
+    wait_vm<12 + 3 * S>(); tile(3); issue(7);          // S0 D4 S1 D5 S2 D6
+    wait_vm<12 + 3 * S>(); tile(4);                    // S1 D5 S2 D6 S3 D7
+    wait_vm<8 + 3 * S>(); tile(5);                     // S2 D6 S3 D7 S4
+    wait_vm<4 + 3 * S>(); tile(6);                     // S3 D7 S4 S5
+    wait_vm<3 * S>(); tile(7);                         // S4 S5 S6
+    static_assert(12 + 3 * S <= 63, "vmcnt is a 6-bit counter");
 }
 
 // SPEC: the epilogue specialisation (EPI_SPEC_*, gemm_common.h)
@@ -177,6 +203,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const
 
     const int nk = p.K / BK;
     const int frow = lane & 15, fq = lane >> 4;
+    // folded LayerNorm, consumer side: (mean, rstd) of this lane's eight rows, in flight during the K loop
+    constexpr bool LN = SPEC == EPI_SPEC_OWN_LN || SPEC == EPI_SPEC_OWN_GELU_LN;
+    f32x2 rs[LN ? 8 : 1];
+    if constexpr (LN) rowstat_prefetch<8>(p, rs, m0 + wm * 128 + frow);
     // fragment read offsets inside a region (the same for both k-steps up to the chunk index)
     int a_off[4][2], b_off[2][2];
 #pragma unroll
@@ -265,19 +295,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const
     }
     if (!group1) phase_barrier();     // every wave executes the same number of barriers
 
-    if (SPEC == EPI_SPEC_F32_RES32) {
+    if (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_F32_RES32_EMIT) {
         // whole 128 x 64 wave blocks of 16-byte aligned rows take the DMA-fed epilogue (wave-uniform choice)
         const int m_wave0 = m0 + wm * 128, n_wave0 = n0 + wn * 64;
         const bool aligned = ((p.ldr | p.ldc) & 3) == 0 && (((uintptr_t)p.resid | (uintptr_t)p.out) & 15) == 0;
         if (__builtin_amdgcn_readfirstlane(m_wave0 + 128 <= p.M && n_wave0 + 64 <= p.N && aligned)) {
             scale_acc<8, 4>(p, acc);
-            epilogue_res32_dma(p, acc, m_wave0, n_wave0, smem + wave * 16384);
+            epilogue_res32_dma<SPEC == EPI_SPEC_F32_RES32_EMIT, T>(p, acc, m_wave0, n_wave0, smem + wave * 16384);
             return;
         }
     }
     // (the staging area of a wave lies inside its own 16 KiB, so waves of one workgroup may take different epilogues)
     static_assert(STAGE_BYTES <= 16384, "a wave's staging area must fit its 16 KiB share of the tile buffers");
-    gemm_epilogue_spec<SPEC, T, 8, 4>(p, acc, m0 + wm * 128 + frow, n0 + wn * 64 + fq * 4, fq, smem + wave * 16384);
+    gemm_epilogue_spec<SPEC, T, 8, 4, LN>(p, acc, m0 + wm * 128 + frow, n0 + wn * 64 + fq * 4, fq, smem + wave * 16384, nullptr, rs);
 }
 
 template <typename T>
@@ -313,6 +343,8 @@ int launch_t(const VdaGemmArgs& a, hipStream_t s) {
             VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_F32_RES32) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN_RES)
             VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN_RES32) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_GEGLU)
             VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_F32) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_CONVT)
+            VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN_LN) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN_GELU_LN)
+            VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_F32_RES32_EMIT)
             default: VDA_LAUNCH256(VDA_A_LINEAR, false, EPI_SPEC_GENERAL);
         }
     }

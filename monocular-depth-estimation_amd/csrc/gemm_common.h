@@ -47,6 +47,71 @@ __device__ __forceinline__ void store4(void* out, int out_type, size_t idx, f32x
     }
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), every lane gets the total.  The four steps pair lane c with
+// c^1, c^2 (quad permutes), c^7 (mirror within 8) and c^15 (mirror within 16); after each step the partial sums are uniform
+// over the group just completed, so the result is the balanced tree ((0+1)+(2+3))+((4+5)+(6+7)) ... over the lane index.
+// Every step is an XOR of the lane index, so if the lanes hold the 16 addends in an XOR-permuted order (addend k on lane
+// k ^ r) the same pairs are added in the same tree: the sum does not depend on r, bit for bit.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    v += dpp_move<0x140>(v);     // row_mirror
+    return v;
+}
+
+// Producer side of a folded LayerNorm (VdaGemmArgs.out16 / row_part).  `v` = four consecutive fp32 output values of a row;
+// the 16 lanes of this lane's DPP row hold one 64-column block of that row between them (in any XOR-permuted order).
+// Stores the values rounded to T at byte offset off16 of out16 and, from the lane `writer`, the block's (sum, sum of squares)
+// of the rounded values at byte offset offp of row_part.  The arithmetic is spelled out operation by operation (no contraction) so that every call site adds the
+// same numbers in the same order.
+// (vda_gemm checks that both arrays are below 4 GiB, so the byte offsets fit 32 bits and the stores take the
+// scalar-base + 32-bit-offset form: no 64-bit address registers beside the 128 accumulators.)
+#define VDA_GLOBAL_PTR(T, p) ((T __attribute__((address_space(1)))*)(p))
+template <typename T>
+__device__ __forceinline__ void emit_rounded_row(void* out16, float* row_part, f32x4 v, unsigned off16, unsigned offp, bool in_range, bool writer) {
+#pragma clang fp contract(off)
+    const typename Vec<T>::v4 h = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+    const float r0 = (float)h[0], r1 = (float)h[1], r2 = (float)h[2], r3 = (float)h[3];
+    float s = (r0 + r1) + (r2 + r3);
+    float q = __builtin_fmaf(r1, r1, r0 * r0) + __builtin_fmaf(r3, r3, r2 * r2);
+    s = row16_sum(s);
+    q = row16_sum(q);
+    if (in_range) {
+        *VDA_GLOBAL_PTR(typename Vec<T>::v4, reinterpret_cast<char*>(out16) + off16) = h;
+        if (writer) {
+            const f32x2 o = {s, q};
+            *VDA_GLOBAL_PTR(f32x2, reinterpret_cast<char*>(row_part) + offp) = o;
+        }
+    }
+}
+
+// A field of the kernel's first argument (a VdaGemmArgs passed by value: it starts the kernel-argument segment), loaded
+// where this is called rather than at kernel entry.  The compiler loads every argument field it sees at entry and keeps it
+// for the whole kernel; fields that only an epilogue needs would take scalar registers from the K loop (and, once those
+// run out, end up in vector registers and scratch).  The volatile load pins the scalar load to the call site.
+template <typename F>
+__device__ __forceinline__ F kernarg_field_now(size_t offset) {
+    typedef const volatile F __attribute__((address_space(4))) * src_t;
+    const char __attribute__((address_space(4)))* base = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(src_t)(base + offset);
+}
+
+// Consumer side: (mean, rstd) of this lane's row of each m-tile, fetched before the K loop so that the epilogue does not
+// wait for them.
+template <int TM>
+__device__ __forceinline__ void rowstat_prefetch(const VdaGemmArgs& p, f32x2 (&rs)[TM], int mrow0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = mrow0 + i * 16;
+        rs[i] = m < p.M ? reinterpret_cast<const f32x2*>(p.row_stat)[m] : f32x2{0.f, 0.f};
+    }
+}
+
 // Workgroup -> output tile.  Workgroups b and b + 8 share an XCD, so workgroup ids are first remapped so that each XCD
 // gets a contiguous run of tiles (bijective for any grid size), then tiles are walked in bands of 8 row-tiles x all
 // column-tiles so that the tiles resident together in one XCD share A and W panels in its L2.
@@ -75,9 +140,12 @@ __device__ __forceinline__ void tile_of_workgroup(const GemmTiles& gt, int& tm, 
 // instead of 8-byte pieces scattered over 16 rows.
 constexpr int STAGE_BYTES = 16 * (4 * 16 * 4 + 16);     // 16 rows x (up to 64 fp32 columns + 16 bytes of padding)
 
-template <int TM, int TN>
+// RS_PRE: rs_pre[i] holds (mean, rstd) of this lane's row of m-tile i (rowstat_prefetch).  A compile-time flag, not a null
+// test of the pointer: a pointer to a private array cannot be compared with null at compile time on this target, and the
+// comparison alone would keep the array in scratch memory.
+template <int TM, int TN, bool RS_PRE = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq,
-                                                     char* stage, const f32x4 (*pre)[TN] = nullptr) {
+                                                     char* stage, const f32x4 (*pre)[TN] = nullptr, const f32x2* rs_pre = nullptr) {
     const int lane = threadIdx.x & 63, frow = lane & 15;
     const int esz = p.out_type == VDA_T_F32 ? 4 : 2;
     const bool geglu = p.epi == VDA_EPI_GEGLU;
@@ -99,18 +167,34 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
         ct_ky = tap / p.ct_k;
         ct_kx = tap - ct_ky * p.ct_k;
     }
-    f32x4 bias[TN], gam[TN];
+    f32x4 bias[TN], gam[TN], csum[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = ncol0 + j * 16;
         bias[j] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n - tap_n0) : f32x4{0.f, 0.f, 0.f, 0.f};
         gam[j] = (p.gamma && n < p.N) ? *reinterpret_cast<const f32x4*>(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+        csum[j] = (p.row_stat && n < p.N) ? *reinterpret_cast<const f32x4*>(p.w_colsum + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int c_row = lane / cpr, c_chunk = lane - c_row * cpr;
+    // producer-side fields of a folded LayerNorm, fetched from the kernel arguments here (see kernarg_field_now; every
+    // kernel that reaches this epilogue takes the VdaGemmArgs as its first argument)
+    void* out16 = nullptr;
+    float* row_part = nullptr;
+    unsigned ld16 = 0;
+    if (p.out16) {
+        out16 = kernarg_field_now<void*>(offsetof(VdaGemmArgs, out16));
+        row_part = kernarg_field_now<float*>(offsetof(VdaGemmArgs, row_part));
+        ld16 = (unsigned)kernarg_field_now<int>(offsetof(VdaGemmArgs, ld16));
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = mrow0 + i * 16;                          // this lane's row of the m-tile
         char* srow = stage + frow * rs;
+        f32x2 st = {0.f, 1.f};                                  // folded LayerNorm: (mean, rstd) of row m of A
+        if (p.row_stat) {
+            if constexpr (RS_PRE) st = rs_pre[i];
+            else st = m < p.M ? reinterpret_cast<const f32x2*>(p.row_stat)[m] : f32x2{0.f, 0.f};
+        }
         if (geglu) {
 #pragma unroll
             for (int j = 0; j < TN; j += 2) {
@@ -127,10 +211,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = ncol0 + j * 16;
-                f32x4 v = acc[i][j] + bias[j];
+                f32x4 v;
+                if (p.row_stat) {       // two fused multiply-adds per value, as vectors (they pair up into packed instructions)
+                    const f32x4 nmean = {-st[0], -st[0], -st[0], -st[0]}, rstd = {st[1], st[1], st[1], st[1]};
+                    v = __builtin_elementwise_fma(__builtin_elementwise_fma(nmean, csum[j], acc[i][j]), rstd, bias[j]);
+                } else {
+                    v = acc[i][j] + bias[j];
+                }
                 if (p.act == VDA_ACT_GELU) {
-    #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
                 } else if (p.act == VDA_ACT_RELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -163,15 +253,24 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
                     // other workgroups are still reading out of L2 (+0.6 % on the ViT-L window, neutral on ViT-S)
                     __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.out) + (pix * p.ldc + out_n0 - tap_n0 + col) * esz));
                 }
+                if (p.out16) {
+                    // folded LayerNorm, producer side (64 fp32 columns per wave: the 16 lanes of a DPP row hold one row's block)
+                    const bool ok = mm < p.M && out_n0 + col < n_out;
+                    const f32x4 f = __builtin_bit_cast(f32x4, v);
+                    const unsigned off16 = ((unsigned)mm * ld16 + (unsigned)(out_n0 + col)) * 2u;
+                    const unsigned offp = ((unsigned)mm * (unsigned)(p.N >> 6) + (unsigned)(out_n0 >> 6)) * 8u;
+                    if (p.ab_type == VDA_T_F16) emit_rounded_row<f16>(out16, row_part, f, off16, offp, ok, c_chunk == 0);
+                    else emit_rounded_row<bf16>(out16, row_part, f, off16, offp, ok, c_chunk == 0);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads returned before the next m-tile overwrites the area
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool RS_PRE = false>
 __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq,
-                                              char* stage = nullptr, const f32x4 (*pre)[TN] = nullptr) {
+                                              char* stage = nullptr, const f32x4 (*pre)[TN] = nullptr, const f32x2* rs_pre = nullptr) {
     if (stage && (p.epi == VDA_EPI_PLAIN || p.epi == VDA_EPI_GEGLU || p.epi == VDA_EPI_CONVT)) {
         const int esz = p.out_type == VDA_T_F32 ? 4 : 2;
         const int n_out = p.epi == VDA_EPI_GEGLU ? p.N / 2 : p.N;
@@ -180,7 +279,7 @@ __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)
         // for the transposed convolution a block must not straddle two kernel taps
         if ((p.ldc * esz) % 16 == 0 && (n_out * esz) % 16 == 0 && (cols * esz) % 16 == 0 && (cols * esz) <= 256 &&
             ((uintptr_t)p.out & 15) == 0 && (p.epi != VDA_EPI_CONVT || p.ct_c % cols == 0)) {
-            gemm_epilogue_staged<TM, TN>(p, acc, mrow0, ncol0, fq, stage, pre);
+            gemm_epilogue_staged<TM, TN, RS_PRE>(p, acc, mrow0, ncol0, fq, stage, pre, rs_pre);
             return;
         }
     }
@@ -249,14 +348,24 @@ __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)
             bias_n = co;
             col_off = ((size_t)ky * (p.ct_w * p.ct_k) + kx) * p.ldc + co;
         }
-        f32x4 b = {0.f, 0.f, 0.f, 0.f}, g = {1.f, 1.f, 1.f, 1.f};
+        f32x4 b = {0.f, 0.f, 0.f, 0.f}, g = {1.f, 1.f, 1.f, 1.f}, cs = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) b = *reinterpret_cast<const f32x4*>(p.bias + bias_n);
         if (p.gamma) g = *reinterpret_cast<const f32x4*>(p.gamma + n);
+        if (p.row_stat) cs = *reinterpret_cast<const f32x4*>(p.w_colsum + n);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = mrow0 + i * 16;
             if (m >= p.M) continue;
-            f32x4 v = acc[i][j] + b;
+            f32x4 v;
+            if (p.row_stat) {          // folded LayerNorm: the same two fused multiply-adds as the staged form
+                f32x2 st;
+                if constexpr (RS_PRE) st = rs_pre[i];
+                else st = reinterpret_cast<const f32x2*>(p.row_stat)[m];
+                const f32x4 nmean = {-st[0], -st[0], -st[0], -st[0]}, rstd = {st[1], st[1], st[1], st[1]};
+                v = __builtin_elementwise_fma(__builtin_elementwise_fma(nmean, cs, acc[i][j]), rstd, b);
+            } else {
+                v = acc[i][j] + b;
+            }
             if (p.act == VDA_ACT_GELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
@@ -300,13 +409,23 @@ enum {
     EPI_SPEC_OWN_RELU = 8,       // plain, own-type output, bias, ReLU
     EPI_SPEC_OWN_RES2 = 9,       // plain, own-type output, bias + two own-type residuals
     EPI_SPEC_DOT = 10,           // ReLU, dot with a vector, ReLU: fp32 output (the direct convolution's tail form)
-    EPI_SPEC_CONVT = 11          // transposed-convolution scatter, own-type output, bias
+    EPI_SPEC_CONVT = 11,         // transposed-convolution scatter, own-type output, bias
+    EPI_SPEC_OWN_LN = 12,        // EPI_SPEC_OWN on rows whose LayerNorm is folded in (row_stat / w_colsum)
+    EPI_SPEC_OWN_GELU_LN = 13,   // EPI_SPEC_OWN_GELU, likewise
+    EPI_SPEC_F32_RES32_EMIT = 14 // EPI_SPEC_F32_RES32 that also emits the rounded rows and their partial sums (out16 / row_part)
 };
 
 // the specialisation that describes this call exactly, or EPI_SPEC_GENERAL
 inline int epi_spec_of(const VdaGemmArgs& a) {
     const int own = a.ab_type == VDA_T_F16 ? VDA_T_F16 : VDA_T_BF16;
     if (a.gamma) return EPI_SPEC_GENERAL;
+    if (a.row_stat)
+        return a.out_type == own && a.resid_type == VDA_T_NONE && !a.out16
+                   ? (a.act == VDA_ACT_NONE ? EPI_SPEC_OWN_LN : a.act == VDA_ACT_GELU ? EPI_SPEC_OWN_GELU_LN : EPI_SPEC_GENERAL)
+                   : EPI_SPEC_GENERAL;
+    if (a.out16)
+        return a.out_type == VDA_T_F32 && a.resid_type == VDA_T_F32 && a.act == VDA_ACT_NONE && !a.resid2 ? EPI_SPEC_F32_RES32_EMIT
+                                                                                                       : EPI_SPEC_GENERAL;
     if (a.epi == VDA_EPI_GEGLU) return a.out_type == own ? EPI_SPEC_GEGLU : EPI_SPEC_GENERAL;
     if (a.epi == VDA_EPI_DOT) return EPI_SPEC_DOT;
     if (a.epi == VDA_EPI_CONVT) return a.out_type == own && a.act == VDA_ACT_NONE ? EPI_SPEC_CONVT : EPI_SPEC_GENERAL;
@@ -333,9 +452,15 @@ __device__ __forceinline__ VdaGemmArgs epi_spec_args(const VdaGemmArgs& p) {
     VdaGemmArgs q = p;
     q.gamma = nullptr;
     q.epi = SPEC == EPI_SPEC_GEGLU ? VDA_EPI_GEGLU : SPEC == EPI_SPEC_DOT ? VDA_EPI_DOT : SPEC == EPI_SPEC_CONVT ? VDA_EPI_CONVT : VDA_EPI_PLAIN;
-    q.act = SPEC == EPI_SPEC_OWN_GELU ? VDA_ACT_GELU : SPEC == EPI_SPEC_OWN_RELU ? VDA_ACT_RELU : VDA_ACT_NONE;
-    q.out_type = (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_F32 || SPEC == EPI_SPEC_DOT) ? VDA_T_F32 : own;
-    q.resid_type = (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_OWN_RES32) ? VDA_T_F32
+    q.act = (SPEC == EPI_SPEC_OWN_GELU || SPEC == EPI_SPEC_OWN_GELU_LN) ? VDA_ACT_GELU : SPEC == EPI_SPEC_OWN_RELU ? VDA_ACT_RELU : VDA_ACT_NONE;
+    constexpr bool res32 = SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_F32_RES32_EMIT;
+    q.out_type = (res32 || SPEC == EPI_SPEC_F32 || SPEC == EPI_SPEC_DOT) ? VDA_T_F32 : own;
+    q.ab_type = own;
+    if (SPEC != EPI_SPEC_OWN_LN && SPEC != EPI_SPEC_OWN_GELU_LN) q.row_stat = q.w_colsum = nullptr;
+    else __builtin_assume(q.row_stat != nullptr);
+    if (SPEC != EPI_SPEC_F32_RES32_EMIT) { q.out16 = nullptr; q.row_part = nullptr; }
+    else __builtin_assume(q.out16 != nullptr);
+    q.resid_type = (res32 || SPEC == EPI_SPEC_OWN_RES32) ? VDA_T_F32
                    : (SPEC == EPI_SPEC_OWN_RES || SPEC == EPI_SPEC_OWN_RES2) ? own : VDA_T_NONE;
     if (q.resid_type == VDA_T_NONE) q.resid = nullptr;
     if (SPEC != EPI_SPEC_OWN_RES2) q.resid2 = nullptr;
@@ -353,12 +478,12 @@ __device__ __forceinline__ void scale_acc(const VdaGemmArgs& p, f32x4 (&acc)[TM]
     }
 }
 
-template <int SPEC, typename T, int TM, int TN>
+template <int SPEC, typename T, int TM, int TN, bool RS_PRE = false>
 __device__ __forceinline__ void gemm_epilogue_spec(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq, char* stage,
-                                                   const f32x4 (*pre)[TN] = nullptr) {
+                                                   const f32x4 (*pre)[TN] = nullptr, const f32x2* rs_pre = nullptr) {
     scale_acc<TM, TN>(p, acc);
     const VdaGemmArgs q = epi_spec_args<SPEC, T>(p);
-    gemm_epilogue<TM, TN>(q, acc, mrow0, ncol0, fq, stage, pre);
+    gemm_epilogue<TM, TN, RS_PRE>(q, acc, mrow0, ncol0, fq, stage, pre, rs_pre);
 }
 
 // The fp32 residual of a wave's block (this lane's four columns of each 16x16 tile), fetched into registers BEFORE the K

@@ -57,6 +57,72 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// The rows rounded to T, and (mean, rstd) of the rounded values (two-pass, like layernorm_kernel).  A workgroup owns 16
+// consecutive rows (four per wave), i.e. one whole 128-byte line of `stat`: on this part every XCD has its own L2, and two
+// workgroups that write different bytes of one line may run on different XCDs.
+template <int VEC4, typename T>
+__global__ __launch_bounds__(256) void round_rowstats_kernel(const float* __restrict__ x, T* __restrict__ out,
+                                                             float* __restrict__ stat, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    for (int k = 0; k < 4; ++k) {
+        const int row = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + k;          // wave-uniform
+        if (row >= rows) return;
+        const float* xr = x + (size_t)row * C;
+        T* orow = out + (size_t)row * C;
+        f32x4 v[VEC4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC4; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < C) {
+                const f32x4 f = *reinterpret_cast<const f32x4*>(xr + c);
+                const typename Vec<T>::v4 o = {(T)f[0], (T)f[1], (T)f[2], (T)f[3]};
+                *reinterpret_cast<typename Vec<T>::v4*>(orow + c) = o;
+                v[i] = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+                s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            }
+        }
+        const float mean = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC4; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < C) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / C + eps);
+        if (lane == 0) {
+            stat[2 * (size_t)row] = mean;
+            stat[2 * (size_t)row + 1] = rstd;
+        }
+    }
+}
+
+// One thread per row: the partial (sum, sum of squares) pairs of the row's 64-column blocks, added in block order.
+__global__ __launch_bounds__(256) void rowstats_finish_kernel(const float* __restrict__ part, float* __restrict__ stat, int rows,
+                                                              int slots, float eps) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const float* p = part + (size_t)row * slots * 2;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < slots; ++i) {
+        const float2 v = *reinterpret_cast<const float2*>(p + 2 * i);
+        s += (double)v.x;
+        q += (double)v.y;
+    }
+    const double n = 64.0 * slots;
+    const double mu = s / n;
+    double var = q / n - mu * mu;
+    if (var < 0) var = 0;
+    float2 o;
+    o.x = (float)mu;
+    o.y = (float)(1.0 / sqrt(var + (double)eps));
+    *reinterpret_cast<float2*>(stat + 2 * (size_t)row) = o;
+}
+
 // GroupNorm pass 1: grid (frames, splits), 256 threads.  A block walks every splits-th slab of `ppb` pixels of its frame;
 // thread t < ppb * C/8 owns the 8 channels [8 (t % (C/8)) ..] of pixel row t / (C/8) of each slab and keeps PER-CHANNEL
 // fp32 sums in registers, so no accumulation order depends on scheduling.  The block then reduces them per group in a
@@ -167,6 +233,35 @@ extern "C" int vda_layernorm(const float* x, void* out, const float* weight, con
     else if (C <= 1024) LN_LAUNCH(4);
     else LN_LAUNCH(8);
 #undef LN_LAUNCH
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_round_rowstats(const float* x, void* out16, float* stat, int rows, int C, float eps, int out_type, void* stream) {
+    if (!x || !out16 || !stat || rows <= 0 || C <= 0) return VDA_EINVAL;
+    if (C % 4 != 0 || C > 2048) return VDA_ESHAPE;
+    if (out_type != VDA_T_BF16 && out_type != VDA_T_F16) return VDA_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((rows + 15) / 16), block(256);
+#define RR_LAUNCH(V)                                                                                                          \
+    do {                                                                                                                      \
+        if (out_type == VDA_T_F16)                                                                                            \
+            hipLaunchKernelGGL((round_rowstats_kernel<V, f16>), grid, block, 0, s, x, reinterpret_cast<f16*>(out16), stat, rows, C, eps); \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((round_rowstats_kernel<V, bf16>), grid, block, 0, s, x, reinterpret_cast<bf16*>(out16), stat, rows, C, eps); \
+    } while (0)
+    if (C <= 256) RR_LAUNCH(1);
+    else if (C <= 512) RR_LAUNCH(2);
+    else if (C <= 1024) RR_LAUNCH(4);
+    else RR_LAUNCH(8);
+#undef RR_LAUNCH
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_rowstats_finish(const float* part, float* stat, int rows, int slots, float eps, void* stream) {
+    if (!part || !stat || rows <= 0 || slots <= 0) return VDA_EINVAL;
+    if (((uintptr_t)part & 7) != 0 || ((uintptr_t)stat & 7) != 0) return VDA_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(rowstats_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, part, stat, rows, slots, eps);
     return hip_rc(hipGetLastError());
 }
 

@@ -11,6 +11,8 @@ fp32 instead of 16-bit; each GEMM operand is split into bf16 [hi | lo | hi] trip
 packed [hi | hi | lo]), so the same MFMA kernels accumulate the three-term hi/lo product over K' = 3K.
 torch is used for allocation (caching allocator = workspace reuse) and the stream only.
 """
+import os
+
 import torch
 
 from . import hip
@@ -36,6 +38,8 @@ class Engine:
         self.side_streams = []
         self.head_streams = 2         # 2: parts of the head run on the first side stream beside the rest (see head())
         self.kept = None              # encoder outputs of the last keyed forward() (see forward)
+        # 16-bit mode: the encoder blocks' LayerNorms are folded into the qkv / fc1 products (see encoder_frames)
+        self.fold_layernorm = not self.split and os.environ.get("VDA_FOLD_LAYERNORM", "1") != "0"
 
     # ---- small wrappers -------------------------------------------------------------------------------------------
     def operand(self, a, relu=False, act=None):
@@ -168,18 +172,42 @@ class Engine:
         att = _empty((M, D), self.edt, dev)
         hid = _empty((M, 4 * D), self.edt, dev)
         tap = 0
+        # Folded LayerNorm (block.py:84,87): no normalisation pass over the residual stream.  The product that updates the
+        # stream (proj, fc2) also writes the updated rows rounded to 16 bits into y, with partial sums per 64 columns;
+        # vda_rowstats_finish turns the sums into (mean, rstd) per row; the next product (fc1, qkv) reads y as it is, with
+        # weights that carry the norm's scale, and normalises its sums in the epilogue.  The very first norm reads rows no
+        # product wrote: one rounding pass (vda_round_rowstats).
+        fold = self.fold_layernorm and D % 64 == 0
+        if fold:
+            slots = D // 64
+            part = _empty((M, slots, 2), torch.float32, dev)
+            stat = _empty((M, 2), torch.float32, dev)
+            hip.round_rowstats(xs, y, stat, M, D, 1e-6)
+            last = len(w.blocks) - 1
         for i, b in enumerate(w.blocks):
-            hip.layernorm(xs, y, b["ln1_w"], b["ln1_b"], M, D, 1e-6)
-            self.linear(y, b["wqkv"], qkv, b["bqkv"])
-            hip.attention(qkv, att, frames, N, heads)
-            self.linear(att, b["wproj"], xs, b["bproj"], resid=xs, ldr=D)         # LayerScale is folded into the weights
-            hip.layernorm(xs, y, b["ln2_w"], b["ln2_b"], M, D, 1e-6)
-            if self.split:      # fp32 storage: fc1 stores its pre-activation, the exact GELU runs in fc2's operand split
-                self.linear(y, b["wfc1"], hid, b["bfc1"])
-                self.linear(hid, b["wfc2"], xs, b["bfc2"], a_act=hip.SPLIT_GELU, resid=xs, ldr=D)
+            if fold:
+                self.linear(y, b["wqkv_ln"], qkv, b["bqkv_ln"], row_stat=stat, w_colsum=b["cs_qkv"])
+                hip.attention(qkv, att, frames, N, heads)
+                self.linear(att, b["wproj"], xs, b["bproj"], resid=xs, ldr=D, out16=y, row_part=part)
+                hip.rowstats_finish(part, stat, M, slots, 1e-6)
+                self.linear(y, b["wfc1_ln"], hid, b["bfc1_ln"], act=hip.ACT_GELU, row_stat=stat, w_colsum=b["cs_fc1"])
+                if i == last:       # nothing reads the rounded rows of the last block (the tap norm below reads the fp32 stream)
+                    self.linear(hid, b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D)
+                else:
+                    self.linear(hid, b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D, out16=y, row_part=part)
+                    hip.rowstats_finish(part, stat, M, slots, 1e-6)
             else:
-                self.linear(y, b["wfc1"], hid, b["bfc1"], act=hip.ACT_GELU)
-                self.linear(hid, b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D)
+                hip.layernorm(xs, y, b["ln1_w"], b["ln1_b"], M, D, 1e-6)
+                self.linear(y, b["wqkv"], qkv, b["bqkv"])
+                hip.attention(qkv, att, frames, N, heads)
+                self.linear(att, b["wproj"], xs, b["bproj"], resid=xs, ldr=D)         # LayerScale is folded into the weights
+                hip.layernorm(xs, y, b["ln2_w"], b["ln2_b"], M, D, 1e-6)
+                if self.split:      # fp32 storage: fc1 stores its pre-activation, the exact GELU runs in fc2's operand split
+                    self.linear(y, b["wfc1"], hid, b["bfc1"])
+                    self.linear(hid, b["wfc2"], xs, b["bfc2"], a_act=hip.SPLIT_GELU, resid=xs, ldr=D)
+                else:
+                    self.linear(y, b["wfc1"], hid, b["bfc1"], act=hip.ACT_GELU)
+                    self.linear(hid, b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D)
             if i in w.taps:
                 t = taps[tap][f0 * hw:f1 * hw]
                 tap += 1

@@ -20,7 +20,7 @@ GROUPNORM_MAX_SPLITS = 64        # VDA_GROUPNORM_MAX_SPLITS: sizes the scratch o
 LSQ_SUMS_DOUBLES = 5 + 4 * 256   # VDA_LSQ_SUMS_DOUBLES: five totals + per-workgroup partials of scale_shift_sums()
 
 EXPORTS = [
-    "vda_version", "vda_gemm", "vda_gemm_kernel_choice", "vda_attention", "vda_layernorm", "vda_groupnorm", "vda_groupnorm_static", "vda_bilinear_nhwc", "vda_bilinear_f32",
+    "vda_version", "vda_gemm", "vda_gemm_kernel_choice", "vda_attention", "vda_layernorm", "vda_round_rowstats", "vda_rowstats_finish", "vda_groupnorm", "vda_groupnorm_static", "vda_bilinear_nhwc", "vda_bilinear_f32",
     "vda_im2col_patch14", "vda_assemble_tokens", "vda_temporal_attention", "vda_scale_shift_sums", "vda_solve_scale_shift",
     "vda_affine_blend", "vda_preprocess_u8", "vda_split3", "vda_sample_points", "vda_scale_frames", "vda_minmax_f32", "vda_colorize_u8",
 ]
@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("in_h", C.c_int), ("in_w", C.c_int), ("cin", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int), ("stride", C.c_int),
         ("ct_h", C.c_int), ("ct_w", C.c_int), ("ct_k", C.c_int), ("ct_c", C.c_int), ("tile_cfg", C.c_int),
         ("up_h", C.c_int), ("up_w", C.c_int), ("acc_scale", C.c_float), ("cin_used", C.c_int),
+        ("out16", C.c_void_p), ("row_part", C.c_void_p), ("ld16", C.c_int), ("row_stat", C.c_void_p), ("w_colsum", C.c_void_p),
     ]
 
 
@@ -57,6 +58,8 @@ def lib():
         l.vda_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.vda_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
                                     C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.vda_round_rowstats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        l.vda_rowstats_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
         l.vda_groupnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_float, C.c_int, C.c_void_p]
         l.vda_groupnorm_static.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -125,12 +128,15 @@ def zero_page(device):
 
 def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr=0, resid2=None, ldr2=0, act=ACT_NONE,
          epi=EPI_PLAIN, relu_in=False, conv=None, convt=None, dot_w=None, dot_b=0.0, tile_cfg=None, upsample_from=None,
-         acc_scale=1.0, cin_used=0):
+         acc_scale=1.0, cin_used=0, out16=None, row_part=None, row_stat=None, w_colsum=None):
     """Enqueue one vda_gemm.  ``conv`` = (in_h, in_w, cin, out_h, out_w, stride); ``convt`` = (h, w, k, c);
     ``upsample_from`` = (h, w) of the map ``a`` that is bilinearly resampled to in_h x in_w on the fly;
     ``acc_scale`` multiplies every sum before the epilogue (operands pre-scaled by powers of two); ``cin_used``: only the
-    first so many channels of every input pixel are multiplied (direct 3x3 kernel only)."""
-    _dev(a, w, out, bias, gamma, resid, resid2, dot_w)
+    first so many channels of every input pixel are multiplied (direct 3x3 kernel only).
+    Folded LayerNorm: ``out16`` [M, >= N] (a's type) and ``row_part`` fp32 [M, N // 64, 2] make the product also emit its
+    output rows rounded to 16 bits with their partial sums; ``row_stat`` fp32 [M, 2] and ``w_colsum`` fp32 [N] make it
+    normalise its sums with the (mean, rstd) of the rows of ``a`` (see VdaGemmArgs in include/vda_hip.h)."""
+    _dev(a, w, out, bias, gamma, resid, resid2, dot_w, out16, row_part, row_stat, w_colsum)
     g = GemmArgs()
     g.a, g.w, g.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
     g.bias = bias.data_ptr() if bias is not None else None
@@ -148,6 +154,14 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
         raise TypeError("vda_gemm: a and w must share one 16-bit type")
     if resid2 is not None and (resid is None or resid2.dtype != resid.dtype):
         raise TypeError("vda_gemm: resid2 needs resid, of the same type")
+    if out16 is not None:
+        if out16.dtype != a.dtype or row_part is None or row_part.dtype != torch.float32:
+            raise TypeError("vda_gemm: out16 has the operands' type and needs an fp32 row_part")
+        g.out16, g.row_part, g.ld16 = out16.data_ptr(), row_part.data_ptr(), out16.stride(0)
+    if row_stat is not None:
+        if w_colsum is None or row_stat.dtype != torch.float32 or w_colsum.dtype != torch.float32:
+            raise TypeError("vda_gemm: row_stat and w_colsum are fp32 and come together")
+        g.row_stat, g.w_colsum = row_stat.data_ptr(), w_colsum.data_ptr()
     g.ab_type = _type(a)
     g.out_type = _type(out)
     g.resid_type = T_NONE if resid is None else _type(resid)
@@ -166,9 +180,11 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
         # the kernel the library picks for this launch, and the epilogue form (= kernel instantiation) it takes
         kernel = KERNEL_NAMES.get(lib().vda_gemm_kernel_choice(C.byref(g)), "?")
         if resid is not None and resid.dtype == torch.float32 and out.dtype == torch.float32 and act == ACT_NONE and resid2 is None:
-            form = "f32_res32"
+            form = "f32_res32_emit" if out16 is not None else "f32_res32"
         elif resid is None and out.dtype == a.dtype:
             form = "own_gelu" if act == ACT_GELU else "own" if act == ACT_NONE else "other"
+            if row_stat is not None and form != "other":
+                form += "_ln"
         else:
             form = "other"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -187,7 +203,8 @@ _TYPE_NAMES = {T_BF16: "bf16", T_F16: "f16"}
 class GemmTiming:
     """Per-launch HIP-event timing of the plain linear GEMMs, tagged (kernel, epilogue form, operand type): the kernel is the
     one the library reports for the launch (vda_gemm_kernel_choice), the form is the kernel instantiation the epilogue
-    takes: "f32_res32" (proj, fc2), "own_gelu" (fc1), "own" (qkv and others).  The events are recorded on the stream the
+    takes: "f32_res32" (proj, fc2; "f32_res32_emit" when they also emit the rounded rows for a folded LayerNorm), "own_gelu"
+    (fc1), "own" (qkv and others); "_ln" marks the forms that normalise their sums (folded LayerNorm).  The events are recorded on the stream the
     kernel is launched on (torch's current stream); launches on concurrent streams overlap and cannot be told apart this
     way, so time with one stream."""
 
@@ -242,6 +259,18 @@ def layernorm(x, out, weight, bias, rows, Cdim, eps, rows_per_group=None, in_gro
         rows_per_group = in_group = rows
     _check(lib().vda_layernorm(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), rows, Cdim, eps, rows_per_group, in_group,
                                in_skip, _ptr(pe), pe_hw, pe_T, _type(out), _stream()), "vda_layernorm")
+
+
+def round_rowstats(x, out16, stat, rows, Cdim, eps):
+    """fp32 rows -> the rows rounded to ``out16``'s type and ``stat`` [rows, 2] = (mean, rstd) of the rounded values."""
+    _dev(x, out16, stat)
+    _check(lib().vda_round_rowstats(_ptr(x), _ptr(out16), _ptr(stat), rows, Cdim, eps, _type(out16), _stream()), "vda_round_rowstats")
+
+
+def rowstats_finish(part, stat, rows, slots, eps):
+    """Partial sums [rows, slots, 2] written by a product with ``row_part`` -> ``stat`` [rows, 2] = (mean, rstd)."""
+    _dev(part, stat)
+    _check(lib().vda_rowstats_finish(_ptr(part), _ptr(stat), rows, slots, eps, _stream()), "vda_rowstats_finish")
 
 
 def groupnorm(x, out, weight, bias, work, frames, hw, Cdim, groups, eps):

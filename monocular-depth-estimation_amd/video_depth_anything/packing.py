@@ -164,12 +164,27 @@ class PackedWeights:
             # x (gamma W)^T + gamma b, rounded to the operand type once, from the fp32 product.  The residual GEMMs then
             # have a plain "+ bias + residual" epilogue.
             ls1, ls2 = g(b + "ls1.gamma"), g(b + "ls2.gamma")
+            ln1_w, ln1_b, ln2_w, ln2_b = g(b + "norm1.weight"), g(b + "norm1.bias"), g(b + "norm2.weight"), g(b + "norm2.bias")
+            wfc1, bfc1 = g(b + "mlp.fc1.weight"), g(b + "mlp.fc1.bias")
+            folded = {}
+            if precision != "fp32":
+                # LayerNorm folded into the product that follows it (block.py:84,87): with W' = W diag(ln_w) rounded to the
+                # operand type,  LN(x) W^T + b = rstd (x W'^T - mean colsum(W')) + (b + W ln_b).  The product reads the rows
+                # of x rounded to 16 bits (written, with their sums, by the product before it) and normalises its sums.
+                for name, w_, b_, lw, lb in (("qkv", wqkv, bqkv, ln1_w, ln1_b), ("fc1", wfc1, bfc1, ln2_w, ln2_b)):
+                    wl = bf(w_ * lw[None, :])
+                    folded["w" + name + "_ln"] = wl
+                    folded["cs_" + name] = f32(wl.double().sum(1).float())
+                    # (an elementwise product and a row sum, not a matrix-vector product: BLAS routines may add in an order
+                    # that changes from process to process, and ranks must pack bit-identical weights)
+                    folded["b" + name + "_ln"] = f32((b_.double() + (w_.double() * lb.double()[None, :]).sum(1)).float())
             self.blocks.append(dict(
+                **folded,
                 ln1_w=f32(g(b + "norm1.weight")), ln1_b=f32(g(b + "norm1.bias")),
                 wqkv=bf(wqkv), bqkv=f32(bqkv),
                 wproj=bf(ls1[:, None] * g(b + "attn.proj.weight")), bproj=f32(ls1 * g(b + "attn.proj.bias")),
                 ln2_w=f32(g(b + "norm2.weight")), ln2_b=f32(g(b + "norm2.bias")),
-                wfc1=bf(g(b + "mlp.fc1.weight")), bfc1=f32(g(b + "mlp.fc1.bias")),
+                wfc1=bf(wfc1), bfc1=f32(bfc1),
                 wfc2=bf(ls2[:, None] * g(b + "mlp.fc2.weight")), bfc2=f32(ls2 * g(b + "mlp.fc2.bias")),
             ))
 

@@ -101,6 +101,52 @@ def test_shared_library_exports_every_declared_symbol():
     assert set(declared) <= exported
 
 
+def test_packed_weights_fold_the_encoder_layernorms_into_qkv_and_fc1():
+    """The folded form the GEMM epilogues evaluate, rstd (x W'^T - mean colsum(W')) + b', is LayerNorm(x) W^T + b for the same
+    rows x (block.py:84,87 -> attention.py:51, mlp.py:36), up to the one rounding of W' = W diag(ln_weight) to bf16; and the
+    packing uses no BLAS routine whose summation order could differ between the ranks of a job."""
+    from video_depth_anything.packing import ATTENTION_Q_SCALE, PackedWeights
+    cfg = spec.MODEL_CONFIGS["vits"]
+    sd = {k: torch.from_numpy(v) for k, v in spec.synth_state_dict(**cfg, seed=1).items()}
+    pw = PackedWeights(sd, cfg["encoder"], cfg["features"], cfg["out_channels"], torch.device("cpu"))
+    again = PackedWeights(sd, cfg["encoder"], cfg["features"], cfg["out_channels"], torch.device("cpu"))
+    D = 384
+    x = torch.randn(50, D, generator=torch.Generator().manual_seed(0), dtype=torch.float64) * 1.5 + 0.2
+    mean, rstd = x.mean(1, keepdim=True), 1.0 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-6)
+    for i in (0, 7):
+        b, p = pw.blocks[i], f"pretrained.blocks.{i}."
+        for name, wk, bk, nk in (("qkv", "attn.qkv", "attn.qkv", "norm1"), ("fc1", "mlp.fc1", "mlp.fc1", "norm2")):
+            w, bias = sd[p + wk + ".weight"].double().clone(), sd[p + bk + ".bias"].double().clone()
+            if name == "qkv":
+                w[:D] *= ATTENTION_Q_SCALE
+                bias[:D] *= ATTENTION_Q_SCALE
+            want = F.layer_norm(x, (D,), sd[p + nk + ".weight"].double(), sd[p + nk + ".bias"].double(), 1e-6) @ w.t() + bias
+            wl, cs, bl = b[f"w{name}_ln"].double(), b[f"cs_{name}"].double(), b[f"b{name}_ln"].double()
+            got = rstd * (x @ wl.t() - mean * cs[None, :]) + bl[None, :]
+            assert (got - want).abs().max() <= 4e-3 * want.abs().max(), (i, name)          # bf16 rounding of W' only
+            assert torch.equal(cs.float(), wl.sum(1).float())
+            for key in (f"w{name}_ln", f"cs_{name}", f"b{name}_ln"):
+                assert torch.equal(b[key], again.blocks[i][key])
+    assert "wqkv_ln" not in PackedWeights(sd, cfg["encoder"], cfg["features"], cfg["out_channels"], torch.device("cpu"),
+                                          precision="fp32").blocks[0]           # the fp32 mode keeps the separate pass
+
+
+def test_gemm_argument_struct_matches_the_header():
+    """hip.GemmArgs mirrors VdaGemmArgs field by field: compile the header and compare size and the offsets of the last fields."""
+    import ctypes
+    import tempfile
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "vda_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu\\n", ' \
+          'sizeof(VdaGemmArgs), offsetof(VdaGemmArgs, acc_scale), offsetof(VdaGemmArgs, out16), offsetof(VdaGemmArgs, ld16), ' \
+          'offsetof(VdaGemmArgs, w_colsum)); return 0; }\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
+        size, *offs = (int(v) for v in subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split())
+    G = hip.GemmArgs
+    assert ctypes.sizeof(G) == size
+    assert [G.acc_scale.offset, G.out16.offset, G.ld16.offset, G.w_colsum.offset] == offs
+
+
 # ---- stand-ins for the device entry points used by the host pipeline ------------------------------------------------
 def _standins(monkeypatch):
     def preprocess_u8(u8, out, frames, h0, w0, H, W):

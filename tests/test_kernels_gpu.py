@@ -414,6 +414,99 @@ def test_layernorm_drop_class_token_and_position_table():
     close(out, want.reshape(B * T, hw, C), BF_OUT, "layernorm + pe")
 
 
+# ---- LayerNorm folded into the products around it (VdaGemmArgs.out16 / row_part / row_stat / w_colsum) --------------------------
+def _stats_of(rounded):
+    v = rounded.double()
+    mean = v.mean(1)
+    return mean, 1.0 / torch.sqrt(v.var(1, unbiased=False) + 1e-6)
+
+
+@pytest.mark.parametrize("dt", HALVES)
+@pytest.mark.parametrize("rows,C", [(2740, 1024), (100, 384), (37, 64), (5, 192)])
+def test_round_rowstats(rows, C, dt):
+    x = rnd((rows, C), 1, 2.0, torch.float32) + 0.5
+    out = torch.empty((rows, C), dtype=dt, device=DEV)
+    stat = torch.full((rows, 2), float("nan"), dtype=torch.float32, device=DEV)
+    hip.round_rowstats(x, out, stat, rows, C, 1e-6)
+    assert torch.equal(out, x.to(dt))                       # one rounding, nothing else
+    mean, rstd = _stats_of(out)
+    close(stat[:, 0].double(), mean, 2e-6, "mean of the rounded rows")
+    close(stat[:, 1].double(), rstd, 2e-6, "rstd of the rounded rows")
+
+
+@pytest.mark.parametrize("cfg", [1, 2])
+@pytest.mark.parametrize("dt", HALVES)
+@pytest.mark.parametrize("M,N,K", [(1370, 1024, 1024), (333, 384, 1536), (256, 128, 64), (700, 1024, 4096)])
+def test_gemm_emits_rounded_rows_and_partial_sums(M, N, K, dt, cfg):
+    """Producer side: the fp32 output is unchanged, out16 is that output rounded once, row_part holds the sums of the ROUNDED
+    values per 64-column block, and vda_rowstats_finish turns them into the rows' mean and 1/std.  Interior tiles take the
+    DMA epilogue of the 256x256 kernel, the rows cut by M its staged one; the 128x128 kernel always the staged one."""
+    a, w = rnd((M, K), 1, 1.0, dt), rnd((N, K), 2, 1 / math.sqrt(K), dt)
+    bias = rnd((N,), 3, 0.1, torch.float32)
+    resid = rnd((M, N), 5, 1.0, torch.float32) + 0.25
+    plain = resid.clone()
+    hip.gemm(a, w, plain, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, resid=plain, ldr=N, tile_cfg=cfg)
+    x = resid.clone()
+    x16 = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+    part = torch.full((M, N // 64, 2), float("nan"), dtype=torch.float32, device=DEV)
+    hip.gemm(a, w, x, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, resid=x, ldr=N, out16=x16, row_part=part, tile_cfg=cfg)
+    assert torch.equal(x, plain)                             # the emitting form computes the same fp32 rows, bit for bit
+    assert torch.equal(x16, x.to(dt))
+    blocks = x16.double().reshape(M, N // 64, 64)
+    close(part[..., 0].double(), blocks.sum(2), 1e-6, "block sums")
+    close(part[..., 1].double(), (blocks * blocks).sum(2), 1e-6, "block sums of squares")
+    stat = torch.full((M, 2), float("nan"), dtype=torch.float32, device=DEV)
+    hip.rowstats_finish(part, stat, M, N // 64, 1e-6)
+    mean, rstd = _stats_of(x16)
+    close(stat[:, 0].double(), mean, 1e-5, "mean")
+    close(stat[:, 1].double(), rstd, 1e-5, "rstd")
+
+
+def test_emitted_partial_sums_do_not_depend_on_the_row_position():
+    """The same rows give the same sums, bit for bit, wherever they lie: in an interior 256-row tile (DMA epilogue), in the tile
+    cut by M (staged epilogue), on the 128x128 kernel.  A frame's result must not depend on the batch it is computed in."""
+    N, K = 1024, 1024
+    a, w = rnd((600, K), 1), rnd((N, K), 2, 1 / math.sqrt(K))
+    resid = rnd((600, N), 5, 1.0, torch.float32)
+
+    def run(rows, cfg):
+        M = len(rows)
+        x = resid[rows].clone()
+        x16 = torch.empty((M, N), dtype=BF, device=DEV)
+        part = torch.empty((M, N // 64, 2), dtype=torch.float32, device=DEV)
+        hip.gemm(a[rows].contiguous(), w, x, M=M, N=N, K=K, lda=K, ldc=N, resid=x, ldr=N, out16=x16, row_part=part, tile_cfg=cfg)
+        return x16, part
+
+    all_rows = torch.arange(600, device=DEV)
+    x16, part = run(all_rows, 2)                      # rows 0..511 interior, 512..599 in the cut tile
+    for rows, cfg in ((all_rows[500:600], 2), (all_rows[0:100], 2), (all_rows[200:333], 1), (all_rows[512:600], 1)):
+        x16_b, part_b = run(rows, cfg)
+        assert torch.equal(x16_b, x16[rows]) and torch.equal(part_b, part[rows]), (int(rows[0]), cfg)
+
+
+@pytest.mark.parametrize("cfg", [1, 2])
+@pytest.mark.parametrize("dt", HALVES)
+@pytest.mark.parametrize("M,N,K,gelu", [(1370, 3072, 1024, False), (333, 1536, 384, True), (300, 4096, 1024, True), (40, 192, 64, False)])
+def test_gemm_normalises_its_sums_like_a_layernorm_in_front(M, N, K, gelu, dt, cfg):
+    """Consumer side: with W' = W diag(g) and colsum(W'), rstd (x W'^T - mean colsum) + (b + W beta) is LayerNorm(x) W^T + b."""
+    x = rnd((M, K), 1, 2.0, torch.float32) + 0.3
+    lw, lb = rnd((K,), 2, 0.3, torch.float32) + 1.0, rnd((K,), 3, 0.2, torch.float32)
+    wgt, bias = rnd((N, K), 4, 1 / math.sqrt(K), torch.float32), rnd((N,), 6, 0.1, torch.float32)
+    x16 = torch.empty((M, K), dtype=dt, device=DEV)
+    stat = torch.empty((M, 2), dtype=torch.float32, device=DEV)
+    hip.round_rowstats(x, x16, stat, M, K, 1e-6)
+    wl = (wgt * lw[None, :]).to(dt)
+    cs = wl.double().sum(1).float()
+    bl = (bias.double() + wgt.double() @ lb.double()).float()
+    out = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+    hip.gemm(x16, wl, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bl, act=hip.ACT_GELU if gelu else hip.ACT_NONE,
+             row_stat=stat, w_colsum=cs, tile_cfg=cfg)
+    want = F.layer_norm(x16.float(), (K,), lw, lb, 1e-6) @ wgt.t() + bias          # the fold is exact for the ROUNDED rows ...
+    if gelu:
+        want = F.gelu(want)
+    close(out, want, 1.2e-2 if dt == BF else 2e-3, "folded layernorm")            # ... up to the rounding of W' and the output
+
+
 @pytest.mark.parametrize("dt", STORAGE)
 @pytest.mark.parametrize("frames,hw,C", [(4, 37 * 37, 256), (3, 100, 192), (2, 361, 384), (2, 50, 64)])
 def test_groupnorm(frames, hw, C, dt):

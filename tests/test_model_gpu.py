@@ -89,6 +89,31 @@ def test_concurrent_streams_do_not_change_a_bit(vits, fp32):
         model.encoder_streams, model.head_streams, model.precision = saved
 
 
+@pytest.mark.parametrize("shape,reps", [((1, 2, 3, 1036, 1036), 12), ((1, 32, 3, 518, 518), 12), ((1, 4, 3, 518, 686), 8)])
+def test_concurrent_streams_do_not_change_a_bit_at_full_size(vits, shape, reps):
+    """The same at the sizes where the kernels of the two frame groups really overlap on the chip (tens of workgroups each, for
+    milliseconds).  At 1036 x 1036 (two groups of one 5477-token frame) an earlier form of the 128x128 kernel's folded-LayerNorm
+    variant, which fetched the row statistics ahead of its K loop, gave different 16-row blocks from run to run as soon as the
+    groups overlapped, and only then: one stream, or small inputs, never showed it.  Forward passes are also issued back to
+    back without a host synchronisation, as a rank does for a block of windows."""
+    model, _ = vits
+    x = torch.from_numpy(np.random.RandomState(21).standard_normal(shape).astype(np.float32)).cuda()
+    saved = model.encoder_streams, model.head_streams
+    try:
+        model.encoder_streams, model.head_streams = 1, 1
+        want = model(x).clone()
+        model.encoder_streams, model.head_streams = 2, 2
+        for rep in range(reps):
+            if rep % 2:
+                a, b = model(x), model(x)
+                assert torch.equal(a, want) and torch.equal(b, want), rep
+            else:
+                assert torch.equal(model(x), want), rep
+                torch.cuda.synchronize()
+    finally:
+        model.encoder_streams, model.head_streams = saved
+
+
 @pytest.mark.parametrize("fp32", [False, True])
 def test_encoder_outputs_carried_between_windows_change_nothing(vits, fp32):
     """A window takes the encoder outputs of the frames it shares with the window before it from that window.  The same

@@ -1,0 +1,36 @@
+"""Repeat one forward pass many times and count outputs that differ from the first, bit for bit.
+    python tools/race_hunt.py [encoder] [H] [W] [T] [repeats]      (VDA_FOLD_LAYERNORM / VDA_ENCODER_STREAMS select the variant)"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "monocular-depth-estimation_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from video_depth_anything import spec  # noqa: E402
+from video_depth_anything.video_depth import VideoDepthAnything  # noqa: E402
+
+enc = sys.argv[1] if len(sys.argv) > 1 else "vits"
+H, W, T, reps = (int(v) for v in (sys.argv[2:6] + ["28", "42", "32", "200"][len(sys.argv) - 2:]))
+model = VideoDepthAnything(**spec.MODEL_CONFIGS[enc])
+model.load_state_dict({k: torch.from_numpy(v) for k, v in spec.synth_state_dict(**spec.MODEL_CONFIGS[enc], seed=3).items()})
+model = model.to("cuda").eval()
+x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, T, 3, H, W)).astype(np.float32)).cuda()
+first = model(x).clone()
+bad = 0
+worst = 0.0
+for i in range(reps):
+    if i % 2:           # back to back, no host synchronisation in between (as a block of windows is enqueued)
+        a = model(x)
+        b = model(x)
+        outs = [a, b]
+    else:
+        outs = [model(x)]
+        torch.cuda.synchronize()
+    for o in outs:
+        if not torch.equal(o, first):
+            bad += 1
+            worst = max(worst, float((o - first).abs().max() / first.abs().max()))
+print(f"{enc} {H}x{W} T={T} fold={os.environ.get('VDA_FOLD_LAYERNORM', '1')} streams={os.environ.get('VDA_ENCODER_STREAMS', '2')}: "
+      f"{bad} outputs differ from the first (worst {worst:.2e})", flush=True)
