@@ -35,6 +35,10 @@ __device__ __forceinline__ f32x4 load4(const void* p, int type, size_t idx) {
     return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
 }
 
+__device__ __forceinline__ float sat_f16(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+__device__ __forceinline__ float sat_as(float v, f16) { return sat_f16(v); }
+__device__ __forceinline__ float sat_as(float v, bf16) { return v; }
+
 __device__ __forceinline__ void store4(void* out, int out_type, size_t idx, f32x4 v) {
     if (out_type == VDA_T_F32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + idx) = v;
@@ -42,7 +46,9 @@ __device__ __forceinline__ void store4(void* out, int out_type, size_t idx, f32x
         bf16x4 b = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
         *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(out) + idx) = b;
     } else {
-        f16x4 b = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        // IEEE half ends at 65504: a larger sum saturates instead of becoming infinite (one more instruction per value; bf16
+        // has fp32's range and needs none)
+        f16x4 b = {(f16)sat_f16(v[0]), (f16)sat_f16(v[1]), (f16)sat_f16(v[2]), (f16)sat_f16(v[3])};
         *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(out) + idx) = b;
     }
 }
@@ -75,7 +81,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <typename T>
 __device__ __forceinline__ void emit_rounded_row(void* out16, float* row_part, f32x4 v, unsigned off16, unsigned offp, bool in_range, bool writer) {
 #pragma clang fp contract(off)
-    const typename Vec<T>::v4 h = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+    const typename Vec<T>::v4 h = {(T)sat_as(v[0], T{}), (T)sat_as(v[1], T{}), (T)sat_as(v[2], T{}), (T)sat_as(v[3], T{})};
     const float r0 = (float)h[0], r1 = (float)h[1], r2 = (float)h[2], r3 = (float)h[3];
     float s = (r0 + r1) + (r2 + r3);
     float q = __builtin_fmaf(r1, r1, r0 * r0) + __builtin_fmaf(r3, r3, r2 * r2);

@@ -739,6 +739,29 @@ def test_attention_fp32_mode(frames, n_tok, heads):
     close(out, want, 3e-6, "attention, fp32 mode")
 
 
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_gemm_fp16_outputs_saturate_instead_of_overflowing(cfg):
+    """A sum beyond the IEEE-half range (a real checkpoint's activation outlier) is stored as +-65504, not as infinity: the
+    reference's own fp16 autocast would give inf here, and one inf turns a whole map into NaN two layers later."""
+    M, N, K = 300, 256, 1024
+    a = torch.full((M, K), 16.0, dtype=torch.float16, device=DEV)
+    w = torch.full((N, K), 8.0, dtype=torch.float16, device=DEV)
+    w[1::2] = -8.0                                             # sums of +-131072
+    w[:, :8] = 0.0
+    w[5] = 0.001                                               # one column in range
+    out = torch.empty((M, N), dtype=torch.float16, device=DEV)
+    hip.gemm(a, w, out, M=M, N=N, K=K, lda=K, ldc=N, tile_cfg=cfg)
+    assert bool(torch.isfinite(out).all())
+    want = (a.float() @ w.float().t()).clamp(-65504.0, 65504.0)
+    assert torch.equal(out[:, 0::2][:, :2], want[:, 0::2][:, :2].half()) and float(out.max()) == 65504.0 and float(out.min()) == -65504.0
+    close(out[:, 5], want[:, 5], 2e-3, "in-range column")
+    r = torch.zeros((M, N), dtype=torch.float32, device=DEV)      # the residual form's rounded copy saturates too
+    y16 = torch.empty((M, N), dtype=torch.float16, device=DEV)
+    part = torch.empty((M, N // 64, 2), dtype=torch.float32, device=DEV)
+    hip.gemm(a, w, r, M=M, N=N, K=K, lda=K, ldc=N, resid=r, ldr=N, out16=y16, row_part=part, tile_cfg=cfg)
+    assert bool(torch.isfinite(y16).all()) and float(y16.max()) == 65504.0 and float(r.max()) > 65504.0
+
+
 def test_rejected_arguments_return_error_codes():
     a = torch.zeros((128, 96), dtype=BF, device=DEV)
     w = torch.zeros((128, 96), dtype=BF, device=DEV)
