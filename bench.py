@@ -8,8 +8,7 @@ HBM.  Windows depend only on input frames, so with N > 1 every rank runs its own
 collective); the reported value is all ranks' frames divided by the slowest rank's time.
 
 The JSON line also carries
-  roofline      : the dominant kernel (the 256x256-tile bf16 MFMA GEMM in the instantiation of the proj / fc2 products,
-                  which also emit the rounded residual rows and their sums for the LayerNorm folded into qkv / fc1) timed
+  roofline      : the dominant kernel (the 256x256-tile bf16 MFMA GEMM in the instantiation of the proj / fc2 products) timed
                   per launch with HIP events on the stream it is launched on: algorithmic FLOP per launch / average launch
                   time vs the dense bf16 peak.  In the timed steps the encoder's two frame groups (and the head's independent
                   branches) run on two streams and their launches overlap, so these times come from a second pass of the same K steps with the groups on
@@ -39,10 +38,10 @@ MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0
 GFLOP_PER_FRAME = {("vitl", 518, 518): 1404.67, ("vits", 518, 518): 121.28, ("vitl", 518, 924): 2761.52,
                    ("vits", 518, 924): 264.43, ("vitl", 1036, 1036): 7822.31, ("vits", 1036, 1036): 898.78,
                    ("vitl", 518, 686): 1938.96, ("vits", 518, 686): 175.41}
-# (kernel, epilogue form, operand type) of the proj / fc2 products: fp32 residual update that also emits the rounded rows and
-# their partial sums for the folded LayerNorm of the next product; without the fold (VDA_FOLD_LAYERNORM=0) the plain form
-DOMINANT = ("gemm256_kernel", "f32_res32_emit", "bf16")
-DOMINANT_UNFOLDED = ("gemm256_kernel", "f32_res32", "bf16")
+# (kernel, epilogue form, operand type) of the proj / fc2 products, the fp32 residual update; with the encoder's LayerNorms
+# folded into qkv / fc1 (VDA_FOLD_LAYERNORM=1; off by default at ViT-L width) the form that also emits the rounded rows
+DOMINANT = ("gemm256_kernel", "f32_res32", "bf16")
+DOMINANT_FOLDED = ("gemm256_kernel", "f32_res32_emit", "bf16")
 TRAFFIC_PROFILE = "profiles/r2_vitl518_hbm_traffic.json"
 
 
@@ -161,6 +160,7 @@ def main():
                                    f"forward, 1x{T}x3x{H}x{W} window resident in HBM, random-init weights",
                        "windows_per_step_per_gpu": 1, "parallelism": f"window-parallel x{world}",
                        "encoder_streams": model.encoder_streams,
+                       "encoder_layernorms": "folded into qkv / fc1" if model._ensure_engine().folds_layernorms() else "separate pass",
                        "operands": "encoder bf16 MFMA, head fp16 MFMA, fp32 accumulate" if args.precision == "half"
                        else "fp32 activations; every product hi*hi + lo*hi + hi*lo on fp16 MFMA, fp32 accumulate",
                        "parity": "16-bit mode: max-rel <= 1e-2 / AbsRel <= 0.5 % on depth maps without clamped pixels, 4-8e-3 of "
@@ -175,10 +175,12 @@ def main():
         timing = kernel_pass(model, x, args.steps)
         # the single kernel with the largest share of the window: the 256x256-tile bf16 GEMM instantiated for an fp32 output
         # with an fp32 residual (the proj and fc2 products, 48 launches per ViT-L window)
-        roof = roofline_of(timing, DOMINANT, "gemm256_kernel<LINEAR, EPI_SPEC_F32_RES32_EMIT, bf16> (encoder proj and fc2)")
-        pmc_name = "gemm256_kernelILi0ELb0ELi14EDF16b"
-        if roof is None:
-            roof = roofline_of(timing, DOMINANT_UNFOLDED, "gemm256_kernel<LINEAR, EPI_SPEC_F32_RES32, bf16> (encoder proj and fc2)")
+        folded = timing.summary(DOMINANT_FOLDED)[0] > timing.summary(DOMINANT)[0]
+        if folded:
+            roof = roofline_of(timing, DOMINANT_FOLDED, "gemm256_kernel<LINEAR, EPI_SPEC_F32_RES32_EMIT, bf16> (encoder proj and fc2)")
+            pmc_name = "gemm256_kernelILi0ELb0ELi14EDF16b"
+        else:
+            roof = roofline_of(timing, DOMINANT, "gemm256_kernel<LINEAR, EPI_SPEC_F32_RES32, bf16> (encoder proj and fc2)")
             pmc_name = "gemm256_kernelILi0ELb0ELi3EDF16b"
         if roof is None:      # ViT-S: the dominant tag is whichever plain GEMM kernel took the most time
             tags = sorted(timing.tags(), key=lambda t: -timing.summary(t)[2])

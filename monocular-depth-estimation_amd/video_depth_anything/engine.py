@@ -38,8 +38,14 @@ class Engine:
         self.side_streams = []
         self.head_streams = 2         # 2: parts of the head run on the first side stream beside the rest (see head())
         self.kept = None              # encoder outputs of the last keyed forward() (see forward)
-        # 16-bit mode: the encoder blocks' LayerNorms are folded into the qkv / fc1 products (see encoder_frames)
-        self.fold_layernorm = not self.split and os.environ.get("VDA_FOLD_LAYERNORM", "1") != "0"
+        # 16-bit mode: the encoder blocks' LayerNorms can be folded into the qkv / fc1 products (see encoder_frames).
+        # None = where it pays: at ViT-S width (+1.2 % on the window).  At ViT-L width the separate pass already hides under
+        # the other stream's matrix-bound kernels (two streams: no gain; one stream +0.7 %) while the residual products,
+        # the kernel with the largest share of the window, slow down by the rows they additionally emit.  True / False
+        # (VideoDepthAnything.fold_layernorm, or VDA_FOLD_LAYERNORM=1 / 0 when the engine is built) force it.
+        env = os.environ.get("VDA_FOLD_LAYERNORM")
+        self.fold_default = None if env is None else env != "0"
+        self.fold_layernorm = self.fold_default
 
     # ---- small wrappers -------------------------------------------------------------------------------------------
     def operand(self, a, relu=False, act=None):
@@ -151,6 +157,11 @@ class Engine:
             main.wait_event(done)
         return taps
 
+    def folds_layernorms(self):
+        """Whether the encoder blocks' LayerNorms are folded into qkv / fc1 on this engine."""
+        D = self.w.D
+        return (D < 1024 if self.fold_layernorm is None else bool(self.fold_layernorm)) and not self.split and D % 64 == 0
+
     def encoder_frames(self, x, f0, f1, H, W, taps):
         """Frames f0..f1-1 through the encoder on the current stream; writes their rows of the tap buffers."""
         w, dev = self.w, self.dev
@@ -177,7 +188,7 @@ class Engine:
         # vda_rowstats_finish turns the sums into (mean, rstd) per row; the next product (fc1, qkv) reads y as it is, with
         # weights that carry the norm's scale, and normalises its sums in the epilogue.  The very first norm reads rows no
         # product wrote: one rounding pass (vda_round_rowstats).
-        fold = self.fold_layernorm and D % 64 == 0
+        fold = self.folds_layernorms()
         if fold:
             slots = D // 64
             part = _empty((M, slots, 2), torch.float32, dev)

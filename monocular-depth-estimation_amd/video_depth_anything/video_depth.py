@@ -88,6 +88,9 @@ class VideoDepthAnything(nn.Module):
         # frames one by one, so a window takes the encoder outputs of those frames from the window before it on this
         # process instead of recomputing them (the temporal head still sees all 32).  False recomputes, like the reference.
         self.reuse_encoder_features = True
+        # 16-bit mode: fold the encoder blocks' LayerNorms (block.py:84,87) into the qkv / fc1 products.  None = the engine's
+        # choice (on at ViT-S width, off at ViT-L width, or what VDA_FOLD_LAYERNORM said when the engine was built)
+        self.fold_layernorm = None
         self._engines = {}            # precision -> (weights key, Engine)
         self._flat = None             # the parameter and buffer tensors, listed once (see _weights_key)
 
@@ -149,6 +152,7 @@ class VideoDepthAnything(nn.Module):
         eng = self._ensure_engine()
         eng.encoder_streams = self.encoder_streams
         eng.head_streams = self.head_streams
+        eng.fold_layernorm = eng.fold_default if self.fold_layernorm is None else bool(self.fold_layernorm)
         with torch.cuda.device(x.device):
             return eng.forward(x.float().contiguous(), frame_keys)
 
