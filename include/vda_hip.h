@@ -106,7 +106,8 @@ typedef struct VdaGemmArgs {
        Producer side (the product that writes the rows x, i.e. proj / fc2 with their residual): */
     void*  out16;         /* NULL = off.  Otherwise ab_type [M][ld16]: every output value rounded to the operand type, stored
                              beside the fp32 output.  Needs out_type F32, EPI_PLAIN, A_LINEAR, N % 64 == 0, N >= 128,
-                             16-byte aligned out rows and 8-byte aligned out16 rows, and row_part                      */
+                             16-byte aligned out rows and 8-byte aligned out16 rows, out16 and row_part each below 4 GiB
+                             (M * ld16 * 2 and M * N/64 * 8 bytes), and row_part; else VDA_ESHAPE                     */
     float* row_part;      /* [M][N/64][2]: for every row and every block of 64 columns the sum and the sum of squares of
                              the ROUNDED values, added in an order that does not depend on where the row lies in a tile
                              (vda_rowstats_finish turns them into mean and 1/std)                                      */
