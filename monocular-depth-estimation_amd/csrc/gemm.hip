@@ -96,6 +96,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const VdaGemmArgs p,
     constexpr bool PRE = (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_F32_RES32_EMIT) && TM * TN <= 16;
     f32x4 pre[PRE ? TM : 1][TN];
     if constexpr (PRE) residual_prefetch<TM, TN>(p, pre, m0 + wm * (BM / WM) + frow, n0 + wn * (BN / WN) + fq * 4);
+    // folded LayerNorm, consumer side: (mean, rstd) of this lane's rows, in flight during the K loop
+    constexpr bool LN = SPEC == EPI_SPEC_OWN_LN || SPEC == EPI_SPEC_OWN_GELU_LN;
+    f32x2 rs[LN ? TM : 1];
+    if constexpr (LN) rowstat_prefetch<TM>(p, rs, m0 + wm * (BM / WM) + frow);
     stage(0, 0);
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) lgkmcnt(0)
     __syncthreads();
@@ -130,11 +134,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const VdaGemmArgs p,
         __syncthreads();   // also drains the in-flight copy of step kt+1 (vmcnt(0) precedes the barrier)
     }
 
-    // (The row statistics of a folded LayerNorm are loaded by the epilogue itself here, one m-tile at a time.  Fetched ahead
-    // of the K loop, as the 256x256 kernel does, this kernel produced wrong 16-row blocks whenever another stream's kernels
-    // shared the chip: not understood, reproducible, and gone with the loads moved here.)
-    gemm_epilogue_spec<SPEC, T, TM, TN>(p, acc, m0 + wm * (BM / WM) + frow, n0 + wn * (BN / WN) + fq * 4, fq, smem + wave * STAGE_BYTES,
-                                        PRE ? pre : nullptr);
+    gemm_epilogue_spec<SPEC, T, TM, TN, LN>(p, acc, m0 + wm * (BM / WM) + frow, n0 + wn * (BN / WN) + fq * 4, fq, smem + wave * STAGE_BYTES,
+                                            PRE ? pre : nullptr, rs);
 }
 
 namespace {

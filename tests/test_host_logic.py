@@ -101,6 +101,29 @@ def test_shared_library_exports_every_declared_symbol():
     assert set(declared) <= exported
 
 
+def test_device_code_has_no_packed_fp32_instruction_that_reads_a_high_register_for_its_low_result(tmp_path):
+    """v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with a source's op_sel bit set (the LOW result reads the HIGH register of
+    the pair) return wrong values in lanes 48..63 on gfx950 while waves of another dispatch issue MFMAs on the same SIMD
+    (tools/micro/pk_opsel_probe.hip; tools/stale_stat_probe.py shows the effect on the encoder).  Kernels of this library
+    run beside each other on concurrent streams, so the built code objects must not hold that form at all."""
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump of the ROCm toolchain is not installed")
+    import shutil
+    lib = shutil.copy(hip.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", os.path.basename(lib)], cwd=tmp_path, capture_output=True, check=True)   # one code object per source
+    objects = sorted(p for p in os.listdir(tmp_path) if p.endswith("gfx950"))
+    assert len(objects) >= 8, objects
+    packed = 0
+    for o in objects:
+        text = subprocess.run([objdump, "-d", o], cwd=tmp_path, capture_output=True, text=True, check=True).stdout
+        lines = [ln for ln in text.splitlines() if re.search(r"\bv_pk_(fma|mul|add)_f32\b", ln)]
+        packed += len(lines)
+        bad = [ln.strip() for ln in lines if "op_sel:[" in ln]
+        assert not bad, (o, len(bad), bad[:3])
+    assert packed > 1000        # the disassembly did see the GEMM epilogues' packed arithmetic
+
+
 def test_packed_weights_fold_the_encoder_layernorms_into_qkv_and_fc1():
     """The folded form the GEMM epilogues evaluate, rstd (x W'^T - mean colsum(W')) + b', is LayerNorm(x) W^T + b for the same
     rows x (block.py:84,87 -> attention.py:51, mlp.py:36), up to the one rounding of W' = W diag(ln_weight) to bf16; and the
