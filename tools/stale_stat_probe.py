@@ -1,11 +1,13 @@
-"""Does a product that reads its row statistics at kernel start see the statistics of the call before?
+"""Is every product that consumes row statistics (folded LayerNorm) bit-identical on two concurrent streams and on one?
 
 The ViT-S encoder loop with the folded LayerNorm, but the statistics each consumer reads carry a tag: `rowstats_finish` runs
-on crafted partial sums that give mean 0 and rstd 1 + (call number mod 7), so every consumer output is rstd_tag * acc + bias
-and a block computed with another call's statistics shows the ratio of the two tags.  One-stream run = reference; the
-two-stream runs are compared call by call and the first differing call of a pass is analysed.
+on crafted partial sums that give mean MEAN and rstd 1 + (call number mod 7), so every consumer output is
+rstd_tag * (acc - MEAN * colsum) + bias, and a block computed with other statistics, or with part of the arithmetic lost,
+shows which.  One stream = reference; the two-stream passes are compared call by call and the first differing call of a
+pass is analysed (which rows and columns, the values against bias / colsum).  This is the probe that traced the wrong
+blocks of an earlier build to a packed fp32 instruction (tools/micro/pk_opsel_probe.hip): their values were exactly the bias.
 
-    VDA_HIP_LIB=tools/exp/libvda_hip_prefetch128.so python tools/stale_stat_probe.py
+    [VDA_HIP_LIB=another build of the library] [MEAN=3] [PASSES=8] [SIZE=1036] python tools/stale_stat_probe.py
 """
 import os
 import sys
@@ -65,14 +67,8 @@ def encoder_frames(self, x, f0, f1, H, W, taps):
     hip.round_rowstats(xs, y, stat, M, D, 1e-6)
     call = [0]
 
-    stat_tmp = _empty((M, 2), torch.float32, dev)
-
     def tag_stats():
-        if os.environ.get("SWAP"):          # the variant under test expects (rstd, mean)
-            hip.rowstats_finish(tagged[call[0] % TAGS], stat_tmp, M, slots, 1e-6)
-            torch.stack((stat_tmp[:, 1], stat_tmp[:, 0]), 1, out=stat)
-        else:
-            hip.rowstats_finish(tagged[call[0] % TAGS], stat, M, slots, 1e-6)
+        hip.rowstats_finish(tagged[call[0] % TAGS], stat, M, slots, 1e-6)
 
     def keep(t):
         CAPTURE[(f0, call[0])] = t.clone()
