@@ -113,6 +113,18 @@ def _dev(*ts):
             raise RuntimeError("libvda_hip operates on device tensors only (got a CPU tensor)")
 
 
+def _need(what, **tensors):
+    """The kernels trust the extents they are given, and a launch that runs past a buffer faults the GPU: refuse, on the
+    host, any call whose shape arguments reach beyond the memory behind a tensor (counted from its first element to the end
+    of its storage, so views into larger buffers pass).  ``tensors``: name = (tensor or None, elements needed)."""
+    for name, (t, elements) in tensors.items():
+        if t is None:
+            continue
+        have = t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+        if elements > have:
+            raise ValueError(f"{what}: {name} holds {have} elements from its first one, the call needs {elements}")
+
+
 _zeros = {}
 
 
@@ -165,6 +177,12 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
     g.ab_type = _type(a)
     g.out_type = _type(out)
     g.resid_type = T_NONE if resid is None else _type(resid)
+    n_out = N // 2 if epi == EPI_GEGLU else N
+    _need("vda_gemm", w=(w, N * K), gamma=(gamma, N), dot_w=(dot_w, N), w_colsum=(w_colsum, N), row_stat=(row_stat, 2 * M),
+          row_part=(row_part, 2 * M * (N // 64)), out16=(out16, (M - 1) * (out16.stride(0) if out16 is not None else 0) + N),
+          a=(a if conv is None else None, (M - 1) * lda + K), bias=(bias if convt is None else None, N),
+          out=(out if convt is None else None, M if epi == EPI_DOT else (M - 1) * ldc + n_out),
+          resid=(resid, (M - 1) * ldr + n_out), resid2=(resid2, (M - 1) * ldr2 + n_out))
     if conv is not None:
         g.a_mode = A_CONV3
         g.in_h, g.in_w, g.cin, g.out_h, g.out_w, g.stride = conv
@@ -238,6 +256,7 @@ def attention(qkv, out, frames, n_tok, heads):
     _dev(qkv, out)
     if qkv.dtype != out.dtype:
         raise TypeError("vda_attention: qkv and out must share one type")
+    _need("vda_attention", qkv=(qkv, frames * n_tok * 3 * heads * 64), out=(out, frames * n_tok * heads * 64))
     _check(lib().vda_attention(_ptr(qkv), _ptr(out), frames, n_tok, heads, _type(qkv), _stream()), "vda_attention")
 
 
@@ -257,6 +276,8 @@ def layernorm(x, out, weight, bias, rows, Cdim, eps, rows_per_group=None, in_gro
     _dev(x, out, weight, bias, pe)
     if rows_per_group is None:
         rows_per_group = in_group = rows
+    _need("vda_layernorm", x=(x, (rows // rows_per_group) * in_group * Cdim), out=(out, rows * Cdim), weight=(weight, Cdim),
+          bias=(bias, Cdim))
     _check(lib().vda_layernorm(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), rows, Cdim, eps, rows_per_group, in_group,
                                in_skip, _ptr(pe), pe_hw, pe_T, _type(out), _stream()), "vda_layernorm")
 
@@ -264,17 +285,20 @@ def layernorm(x, out, weight, bias, rows, Cdim, eps, rows_per_group=None, in_gro
 def round_rowstats(x, out16, stat, rows, Cdim, eps):
     """fp32 rows -> the rows rounded to ``out16``'s type and ``stat`` [rows, 2] = (mean, rstd) of the rounded values."""
     _dev(x, out16, stat)
+    _need("vda_round_rowstats", x=(x, rows * Cdim), out16=(out16, rows * Cdim), stat=(stat, 2 * rows))
     _check(lib().vda_round_rowstats(_ptr(x), _ptr(out16), _ptr(stat), rows, Cdim, eps, _type(out16), _stream()), "vda_round_rowstats")
 
 
 def rowstats_finish(part, stat, rows, slots, eps):
     """Partial sums [rows, slots, 2] written by a product with ``row_part`` -> ``stat`` [rows, 2] = (mean, rstd)."""
     _dev(part, stat)
+    _need("vda_rowstats_finish", part=(part, 2 * rows * slots), stat=(stat, 2 * rows))
     _check(lib().vda_rowstats_finish(_ptr(part), _ptr(stat), rows, slots, eps, _stream()), "vda_rowstats_finish")
 
 
 def groupnorm(x, out, weight, bias, work, frames, hw, Cdim, groups, eps):
     _dev(x, out, weight, bias, work)
+    _need("vda_groupnorm", x=(x, frames * hw * Cdim), out=(out, frames * hw * Cdim), weight=(weight, Cdim), bias=(bias, Cdim))
     _check(lib().vda_groupnorm(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(work), frames, hw, Cdim, groups, eps,
                                _type(x), _stream()), "vda_groupnorm")
 
@@ -285,39 +309,46 @@ GROUPNORM_STATIC_MAX_FRAMES = 64     # VDA_GROUPNORM_STATIC_MAX_FRAMES
 def groupnorm_static(x, out, weight, bias, frames, hw, Cdim, groups, eps):
     """vda_groupnorm with the library's own scratch array (no workspace, no allocation); the tensors' device must be current."""
     _dev(x, out, weight, bias)
+    _need("vda_groupnorm_static", x=(x, frames * hw * Cdim), out=(out, frames * hw * Cdim), weight=(weight, Cdim), bias=(bias, Cdim))
     _check(lib().vda_groupnorm_static(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), frames, hw, Cdim, groups, eps, _type(x),
                                       _stream()), "vda_groupnorm_static")
 
 
 def bilinear_nhwc(x, out, frames, in_h, in_w, out_h, out_w, Cdim):
     _dev(x, out)
+    _need("vda_bilinear_nhwc", x=(x, frames * in_h * in_w * Cdim), out=(out, frames * out_h * out_w * Cdim))
     _check(lib().vda_bilinear_nhwc(_ptr(x), _ptr(out), frames, in_h, in_w, out_h, out_w, Cdim, _type(x), _stream()),
            "vda_bilinear_nhwc")
 
 
 def bilinear_f32(x, out, frames, in_h, in_w, out_h, out_w, relu=False):
     _dev(x, out)
+    _need("vda_bilinear_f32", x=(x, frames * in_h * in_w), out=(out, frames * out_h * out_w))
     _check(lib().vda_bilinear_f32(_ptr(x), _ptr(out), frames, in_h, in_w, out_h, out_w, int(relu), _stream()), "vda_bilinear_f32")
 
 
 def im2col_patch14(x, out, frames, H, W, ldk):
     _dev(x, out)
+    _need("vda_im2col_patch14", x=(x, frames * 3 * H * W), out=(out, frames * (H // 14) * (W // 14) * ldk))
     _check(lib().vda_im2col_patch14(_ptr(x), _ptr(out), frames, H, W, ldk, _type(out), _stream()), "vda_im2col_patch14")
 
 
 def assemble_tokens(tok, cls, pos, x, frames, hw, D):
     _dev(tok, cls, pos, x)
+    _need("vda_assemble_tokens", tok=(tok, frames * hw * D), cls=(cls, D), pos=(pos, (hw + 1) * D), x=(x, frames * (hw + 1) * D))
     _check(lib().vda_assemble_tokens(_ptr(tok), _ptr(cls), _ptr(pos), _ptr(x), frames, hw, D, _stream()), "vda_assemble_tokens")
 
 
 def temporal_attention(qkv, out, batch, T, hw, heads, hd, scale):
     _dev(qkv, out)
+    _need("vda_temporal_attention", qkv=(qkv, batch * T * hw * 3 * heads * hd), out=(out, batch * T * hw * heads * hd))
     _check(lib().vda_temporal_attention(_ptr(qkv), _ptr(out), batch, T, hw, heads, hd, scale, _type(qkv), _stream()),
            "vda_temporal_attention")
 
 
 def scale_shift_sums(pred, target, sums, n):
     _dev(pred, target, sums)
+    _need("vda_scale_shift_sums", pred=(pred, n), target=(target, n))
     _check(lib().vda_scale_shift_sums(_ptr(pred), _ptr(target), _ptr(sums), n, _stream()), "vda_scale_shift_sums")
 
 
@@ -328,11 +359,13 @@ def solve_scale_shift(sums, ss):
 
 def affine_blend(x, pre, out, ss, w_pre, w_post, n):
     _dev(x, pre, out, ss)
+    _need("vda_affine_blend", x=(x, n), pre=(pre, n), out=(out, n), ss=(ss, 2))
     _check(lib().vda_affine_blend(_ptr(x), _ptr(pre), _ptr(out), _ptr(ss), w_pre, w_post, n, _stream()), "vda_affine_blend")
 
 
 def preprocess_u8(frames_u8, out, frames, h0, w0, H, W):
     _dev(frames_u8, out)
+    _need("vda_preprocess_u8", frames_u8=(frames_u8, frames * h0 * w0 * 3), out=(out, frames * 3 * H * W))
     _check(lib().vda_preprocess_u8(_ptr(frames_u8), _ptr(out), frames, h0, w0, H, W, _stream()), "vda_preprocess_u8")
 
 
@@ -341,11 +374,13 @@ def sample_points(depth, xy, out, frames, h, w):
     _dev(depth, xy, out)
     if xy.dtype != torch.int32 or depth.dtype != torch.float32:
         raise TypeError("vda_sample_points: fp32 maps and int32 coordinates")
+    _need("vda_sample_points", depth=(depth, frames * h * w), xy=(xy, 2 * frames), out=(out, frames))
     _check(lib().vda_sample_points(_ptr(depth), _ptr(xy), _ptr(out), frames, h, w, _stream()), "vda_sample_points")
 
 
 def scale_frames(depth, scales, out, frames, hw):
     _dev(depth, scales, out)
+    _need("vda_scale_frames", depth=(depth, frames * hw), scales=(scales, frames), out=(out, frames * hw))
     _check(lib().vda_scale_frames(_ptr(depth), _ptr(scales), _ptr(out), frames, hw, _stream()), "vda_scale_frames")
 
 
@@ -354,9 +389,11 @@ MINMAX_FLOATS = 2 + 2 * 256        # VDA_MINMAX_FLOATS
 
 def minmax_f32(x, minmax, n):
     _dev(x, minmax)
+    _need("vda_minmax_f32", x=(x, n), minmax=(minmax, MINMAX_FLOATS))
     _check(lib().vda_minmax_f32(_ptr(x), _ptr(minmax), n, _stream()), "vda_minmax_f32")
 
 
 def colorize_u8(depth, minmax, lut, out, n):
     _dev(depth, minmax, lut, out)
+    _need("vda_colorize_u8", depth=(depth, n), minmax=(minmax, 2), lut=(lut, 3 * 256), out=(out, n if lut is None else 3 * n))
     _check(lib().vda_colorize_u8(_ptr(depth), _ptr(minmax), _ptr(lut), _ptr(out), n, _stream()), "vda_colorize_u8")

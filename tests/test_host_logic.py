@@ -124,6 +124,21 @@ def test_device_code_has_no_packed_fp32_instruction_that_reads_a_high_register_f
     assert packed > 1000        # the disassembly did see the GEMM epilogues' packed arithmetic
 
 
+def test_wrappers_refuse_extents_beyond_the_tensor_storage():
+    """Every kernel wrapper checks its shape arguments against the memory behind its tensors before it launches (a kernel that
+    runs past a buffer faults the GPU).  The check counts from a view's first element to the end of its storage."""
+    buf = torch.zeros(10, 8)
+    hip._need("t", whole=(buf, 80), none=(None, 10 ** 9))
+    hip._need("t", tail_rows=(buf[6:], 32), column_slice=(buf[:, 2:6], 9 * 8 + 4))      # a view into a wider buffer passes
+    with pytest.raises(ValueError, match="holds 80 elements"):
+        hip._need("t", whole=(buf, 81))
+    with pytest.raises(ValueError, match="holds 32 elements"):
+        hip._need("t", tail_rows=(buf[6:], 33))
+    with pytest.raises(ValueError):                                        # vda_attention with one head too many
+        q = torch.zeros(2 * 5 * 3 * 2 * 64, dtype=torch.bfloat16)
+        hip._need("vda_attention", qkv=(q, 2 * 5 * 3 * 3 * 64))
+
+
 def test_packed_weights_fold_the_encoder_layernorms_into_qkv_and_fc1():
     """The folded form the GEMM epilogues evaluate, rstd (x W'^T - mean colsum(W')) + b', is LayerNorm(x) W^T + b for the same
     rows x (block.py:84,87 -> attention.py:51, mlp.py:36), up to the one rounding of W' = W diag(ln_weight) to bf16; and the
