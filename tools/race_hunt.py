@@ -32,5 +32,5 @@ for i in range(reps):
         if not torch.equal(o, first):
             bad += 1
             worst = max(worst, float((o - first).abs().max() / first.abs().max()))
-print(f"{enc} {H}x{W} T={T} fold={os.environ.get('VDA_FOLD_LAYERNORM', '1')} streams={os.environ.get('VDA_ENCODER_STREAMS', '2')}: "
+print(f"{enc} {H}x{W} T={T} layernorms {'folded' if model._ensure_engine().folds_layernorms() else 'separate'} streams={model.encoder_streams}: "
       f"{bad} outputs differ from the first (worst {worst:.2e})", flush=True)
