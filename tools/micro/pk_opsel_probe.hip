@@ -161,6 +161,60 @@ __global__ __launch_bounds__(256) void victim_form(const f32x2* __restrict__ sta
     if (hi) atomicAdd(&bad[64 + lane], hi);
 }
 
+// The mixed-precision multiply-adds (fp16 halves of 32-bit registers picked by op_sel / op_sel_hi) under the same conditions.
+// x holds two fp16 values in one register; the reference converts the half the modifiers name and uses v_fma_f32.
+template <int F>
+__global__ __launch_bounds__(256) void victim_mix(const f32x2* __restrict__ stat, unsigned* __restrict__ bad, int iters) {
+    const int lane = threadIdx.x & 63;
+    const f32x2 y = stat[(blockIdx.x * 256 + threadIdx.x) & 1023];
+    const float z = 0.125f + lane;
+    unsigned wrong = 0;
+    float hl = 0.5f + lane, hh = 1.25f + 0.5f * lane;           // exactly representable in fp16 for every lane and step below
+    for (int it = 0; it < iters; ++it) {
+#pragma clang fp contract(off)
+        const _Float16 l16 = (_Float16)hl, h16 = (_Float16)hh;
+        const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, l16) | ((unsigned)__builtin_bit_cast(unsigned short, h16) << 16);
+        float t, r;
+        if constexpr (F == 0) {
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(t) : "v"(x), "v"(y[0]), "v"(z));
+            r = __builtin_fmaf((float)l16, y[0], z);
+        } else if constexpr (F == 1) {
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(t) : "v"(x), "v"(y[0]), "v"(z));
+            r = __builtin_fmaf((float)h16, y[0], z);
+        } else if constexpr (F == 2) {
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=&v"(t) : "v"(y[1]), "v"(x), "v"(z));
+            r = __builtin_fmaf(y[1], (float)h16, z);
+        } else {
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=&v"(t) : "v"(x), "v"(x), "v"(z));
+            r = __builtin_fmaf((float)h16, (float)l16, z);
+        }
+        wrong += (t != r);
+        hl += 0.5f;
+        if (hl > 512.f) hl = 0.5f + lane;
+        hh += 0.25f;
+        if (hh > 256.f) hh = 1.25f + 0.5f * lane;
+    }
+    if (wrong) atomicAdd(&bad[lane], wrong);
+}
+
+template <int F>
+void run_mix(const char* name, hipStream_t sa, hipStream_t sb, const f32x2* stat, unsigned* bad, float* sink, const float* src, int blocks, int iters) {
+    for (int beside = 0; beside < 2; ++beside) {
+        CHECK(hipMemset(bad, 0, 128 * sizeof(unsigned)));
+        CHECK(hipDeviceSynchronize());
+        if (beside) hipLaunchKernelGGL(aggressor<1>, dim3(blocks), dim3(256), 0, sb, sink, src, iters * 4);
+        hipLaunchKernelGGL(victim_mix<F>, dim3(blocks), dim3(256), 0, sa, stat, bad, iters);
+        CHECK(hipGetLastError());
+        CHECK(hipDeviceSynchronize());
+        unsigned b[128];
+        CHECK(hipMemcpy(b, bad, sizeof(b), hipMemcpyDeviceToHost));
+        unsigned long long w[4] = {0, 0, 0, 0};
+        for (int l = 0; l < 64; ++l) w[l / 16] += b[l];
+        std::printf("%-58s %s: wrong per 16 lanes %llu %llu %llu %llu\n", name, beside ? "beside MFMA" : "alone      ", w[0], w[1], w[2], w[3]);
+        std::fflush(stdout);
+    }
+}
+
 template <int F>
 void run_form(const char* name, hipStream_t sa, hipStream_t sb, const f32x2* stat, unsigned* bad, float* sink, const float* src, int blocks, int iters) {
     for (int beside = 0; beside < 2; ++beside) {
@@ -248,5 +302,9 @@ int main() {
     run_form<9>("v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[0,0]", sa, sb, stat, bad, sink, src, blocks, fi);
     run_form<10>("v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[1,1]", sa, sb, stat, bad, sink, src, blocks, fi);
     run_form<11>("v_pk_add_f32 op_sel:[1,0] op_sel_hi:[1,1]", sa, sb, stat, bad, sink, src, blocks, fi);
+    run_mix<0>("v_fma_mix_f32 op_sel_hi:[1,0,0]", sa, sb, stat, bad, sink, src, blocks, fi);
+    run_mix<1>("v_fma_mix_f32 op_sel:[1,0,0] op_sel_hi:[1,0,0]", sa, sb, stat, bad, sink, src, blocks, fi);
+    run_mix<2>("v_fma_mix_f32 op_sel:[0,1,0] op_sel_hi:[0,1,0]", sa, sb, stat, bad, sink, src, blocks, fi);
+    run_mix<3>("v_fma_mix_f32 op_sel:[1,0,0] op_sel_hi:[1,1,0]", sa, sb, stat, bad, sink, src, blocks, fi);
     return 0;
 }
