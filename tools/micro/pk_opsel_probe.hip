@@ -161,6 +161,41 @@ __global__ __launch_bounds__(256) void victim_form(const f32x2* __restrict__ sta
     if (hi) atomicAdd(&bad[64 + lane], hi);
 }
 
+// The packed instruction and the MFMA loop inside ONE dispatch.  Workgroup ids go round the eight XCDs, and inside an XCD
+// probably round its CUs, so the role is the parity of the bits of id >> 3: however ids are dealt out in powers of two,
+// every CU gets workgroups of both kinds, and their waves share SIMDs as they do when two kernels overlap.  Launched
+// with 2 * blocks workgroups; workgroup id writes sink[id * 256 ..], and sink holds 2 * blocks * 256 floats.
+__global__ __launch_bounds__(256) void one_dispatch(const f32x2* __restrict__ stat, unsigned* __restrict__ bad, float* __restrict__ sink, int iters) {
+    const int lane = threadIdx.x & 63;
+    if (__popc(blockIdx.x >> 3) & 1) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 fa, fb;
+        for (int i = 0; i < 8; ++i) {
+            fa[i] = (__bf16)(0.01f * (threadIdx.x + i));
+            fb[i] = (__bf16)(0.02f * (threadIdx.x - i));
+        }
+        for (int it = 0; it < iters * 4; ++it) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+        sink[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+        return;
+    }
+    const f32x2 y = stat[(blockIdx.x * 256 + threadIdx.x) & 1023];
+    f32x2 x = {0.5f + lane, 0.25f * lane + 1.0f};
+    const f32x2 z = {0.125f + lane, -0.25f};
+    unsigned lo = 0, hi = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma clang fp contract(off)
+        f32x2 t;
+        float rl, rh;
+        PK3("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]", 0, 1, 0, 1, 1, 1)
+        lo += (t[0] != rl);
+        hi += (t[1] != rh);
+        x[0] += 1.0f;
+        x[1] += 0.125f;
+    }
+    if (lo) atomicAdd(&bad[lane], lo);
+    if (hi) atomicAdd(&bad[64 + lane], hi);
+}
+
 // The mixed-precision multiply-adds (fp16 halves of 32-bit registers picked by op_sel / op_sel_hi) under the same conditions.
 // x holds two fp16 values in one register; the reference converts the half the modifiers name and uses v_fma_f32.
 template <int F>
@@ -249,7 +284,7 @@ int main() {
     float *sink, *src;
     CHECK(hipMalloc(&stat, 1024 * sizeof(f32x2)));
     CHECK(hipMalloc(&bad, 128 * sizeof(unsigned)));
-    CHECK(hipMalloc(&sink, blocks * 256 * sizeof(float)));
+    CHECK(hipMalloc(&sink, 2 * blocks * 256 * sizeof(float)));
     CHECK(hipMalloc(&src, (size_t)(1u << 24) * sizeof(float)));
     CHECK(hipMemset(src, 0, (size_t)(1u << 24) * sizeof(float)));
     std::vector<f32x2> h(1024);
@@ -302,6 +337,23 @@ int main() {
     run_form<9>("v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[0,0]", sa, sb, stat, bad, sink, src, blocks, fi);
     run_form<10>("v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[1,1]", sa, sb, stat, bad, sink, src, blocks, fi);
     run_form<11>("v_pk_add_f32 op_sel:[1,0] op_sel_hi:[1,1]", sa, sb, stat, bad, sink, src, blocks, fi);
+    {
+        CHECK(hipMemset(bad, 0, 128 * sizeof(unsigned)));
+        CHECK(hipDeviceSynchronize());
+        hipLaunchKernelGGL(one_dispatch, dim3(blocks * 2), dim3(256), 0, sa, stat, bad, sink, fi);
+        CHECK(hipGetLastError());
+        CHECK(hipDeviceSynchronize());
+        unsigned b[128];
+        CHECK(hipMemcpy(b, bad, sizeof(b), hipMemcpyDeviceToHost));
+        unsigned long long lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+        for (int l = 0; l < 64; ++l) {
+            lo[l / 16] += b[l];
+            hi[l / 16] += b[64 + l];
+        }
+        std::printf("%-58s %s: low wrong per 16 lanes %llu %llu %llu %llu, high %llu %llu %llu %llu\n", "v_pk_fma_f32 op_sel:[0,1,0]",
+                    "beside MFMA waves of the SAME dispatch", lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
+        std::fflush(stdout);
+    }
     run_mix<0>("v_fma_mix_f32 op_sel_hi:[1,0,0]", sa, sb, stat, bad, sink, src, blocks, fi);
     run_mix<1>("v_fma_mix_f32 op_sel:[1,0,0] op_sel_hi:[1,0,0]", sa, sb, stat, bad, sink, src, blocks, fi);
     run_mix<2>("v_fma_mix_f32 op_sel:[0,1,0] op_sel_hi:[0,1,0]", sa, sb, stat, bad, sink, src, blocks, fi);
