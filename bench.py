@@ -13,6 +13,8 @@ The JSON line also carries
                   time vs the dense bf16 peak.  In the timed steps the encoder's two frame groups (and the head's independent
                   branches) run on two streams and their launches overlap, so these times come from a second pass of the same K steps with the groups on
                   one stream (``--encoder-streams 1`` runs the whole bench that way, as the committed rocprof summary does);
+  fp32_mode     : the same window in the fp32 storage mode (``precision = "fp32"``, what ``infer_video_depth(fp32=True)``
+                  runs): the mode that meets the parity bounds also where the final ReLU clamps pixels to 0; N = 1 only;
   vits          : the same measurement for VDA-Small (the metric names both models), N = 1 only;
   end_to_end    : the whole-video path (`infer_video_depth`) from host frames to host depth, PCIe included (N = 1 only);
   sharded_video : N > 1: one video through `infer_video_depth` with its windows dealt over the ranks (RCCL all-gather of
@@ -62,6 +64,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-vits", action="store_true")
+    ap.add_argument("--no-fp32-mode", action="store_true")
     ap.add_argument("--no-sharded-video", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single device: every rank uses cuda:0 and the gloo backend")
@@ -198,6 +201,11 @@ def main():
             if headline:
                 roof.update(pmc_traffic(pmc_name))
             out["roofline"] = roof
+    if rank == 0 and world == 1 and not args.no_fp32_mode and args.precision == "half":
+        try:
+            out["fp32_mode"] = fp32_mode_line(model, x, timed_steps, args)
+        except Exception as e:      # noqa: BLE001  (an auxiliary block: reported in the line, not swallowed)
+            out["fp32_mode"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     del x
     if rank == 0 and world == 1 and not args.no_vits and args.encoder == "vitl":
         out["vits"] = vits_line(build, timed_steps, kernel_pass, roofline_of, args, dev)
@@ -214,12 +222,38 @@ def main():
         if rank == 0:
             out["sharded_video"] = sv
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.encoder, H, W)
+        out["cpu_baseline"] = cpu_baseline(args.encoder, H, W, T)
+        if args.encoder == "vitl" and not args.no_vits:
+            out["vits"]["cpu_baseline"] = cpu_baseline("vits", 518, 518, 32)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def fp32_mode_line(model, x, timed_steps, args):
+    """The same model and window in the fp32 storage mode: fp32 activations, every product hi*hi + lo*hi + hi*lo of
+    IEEE-half pieces on the 16-bit matrix cores (three times the matrix work of the headline mode)."""
+    steps = max(3, min(args.steps, 6))
+    model.precision = "fp32"
+    try:
+        dt = timed_steps(model, x, steps, 2)
+    finally:
+        model.precision = args.precision
+        model._engines.pop("fp32", None)           # frees the fp32 mode's packed weights and workspaces
+        torch.cuda.empty_cache()
+    T = x.shape[1]
+    fps = steps * T / dt
+    line = {"metric": "frames/sec, fp32 storage mode (infer_video_depth(fp32=True))", "value": round(fps, 2), "unit": "frames/s",
+            "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": 2,
+            "dtype": "f32 activations; products as 3 fp16 hi/lo MFMA passes, fp32 accumulate",
+            "parity": "max-rel <= 1e-2 / AbsRel <= 0.5 % on smooth and on clamped depth maps (tests/test_model_gpu.py)"}
+    gf = GFLOP_PER_FRAME.get((args.encoder, x.shape[3], x.shape[4]))
+    if gf:
+        line["model_tflops"] = round(fps * gf / 1e3, 2)
+        line["matrix_tflops_issued"] = round(3 * fps * gf / 1e3, 2)
+    return line
 
 
 def vits_line(build, timed_steps, kernel_pass, roofline_of, args, dev):
@@ -346,11 +380,10 @@ def cpu_info():
     return model, len(cores)
 
 
-def cpu_baseline(encoder, H, W):
-    """The CPU oracle on a bounded sample of the same workload: 12-frame windows instead of 32 (the per-frame cost of the
-    encoder and the head does not depend on the window length; only the negligible temporal attention does): one 4-frame
-    warm-up window, then two timed 12-frame windows, median reported.  A full 32-frame ViT-L window takes about 40 s on
-    these threads; three of them plus a warm-up would not fit the bench's time limit."""
+def cpu_baseline(encoder, H, W, T=32):
+    """The CPU oracle on the same workload: one 4-frame warm-up window, then three timed full windows (T frames each),
+    median reported.  A 32-frame ViT-L window takes about 40 s on 16 threads, so this leg is most of the bench's wall time;
+    a progress line goes to stderr after every window."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vda_oracle as O
     from video_depth_anything import spec
@@ -361,21 +394,22 @@ def cpu_baseline(encoder, H, W):
     g = torch.Generator().manual_seed(0)
     for k, (shape, kind) in spec.state_dict_spec(**cfg).items():       # throughput does not depend on the values: cheap random fill
         sd[k] = torch.randn(shape, generator=g) * 0.02
-    frames = 12 if encoder == "vitl" else 32
     rs = np.random.RandomState(0)
     O.forward(sd, torch.from_numpy(rs.standard_normal((1, 4, 3, H, W)).astype(np.float32)), encoder)      # warm-up
+    print(f"cpu_baseline {encoder}: warm-up window done", file=sys.stderr, flush=True)
     times = []
-    for _ in range(2):
-        x = torch.from_numpy(rs.standard_normal((1, frames, 3, H, W)).astype(np.float32))
+    for i in range(3):
+        x = torch.from_numpy(rs.standard_normal((1, T, 3, H, W)).astype(np.float32))
         t0 = time.perf_counter()
         O.forward(sd, x, encoder)
         times.append(time.perf_counter() - t0)
+        print(f"cpu_baseline {encoder}: window {i + 1}/3 took {times[-1]:.1f} s", file=sys.stderr, flush=True)
     med = statistics.median(times)
     model, phys = cpu_info()
-    return {"value": round(frames / med, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+    return {"value": round(T / med, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "cpu_model": model, "physical_cores_in_machine": phys, "threads_used": threads,
-            "sample": f"CPU oracle (fp32 torch restatement of the reference), 1 warm-up window of 4 frames + 2 timed windows of "
-                      f"{frames} frames at {H}x{W}; median {med:.1f} s per window ({', '.join(f'{t:.1f}' for t in times)})"}
+            "sample": f"CPU oracle (fp32 torch restatement of the reference), 1 warm-up window of 4 frames + 3 timed windows of "
+                      f"{T} frames at {H}x{W}; median {med:.1f} s per window ({', '.join(f'{t:.1f}' for t in times)})"}
 
 
 if __name__ == "__main__":

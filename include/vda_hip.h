@@ -178,7 +178,9 @@ int vda_groupnorm(const void* x, void* out, const float* weight, const float* bi
  * GPU, held until the process ends.  No counterpart in the reference.  Same results as vda_groupnorm, bit for bit.
  * frames <= VDA_GROUPNORM_STATIC_MAX_FRAMES, else VDA_ESHAPE.  The device that `stream` belongs to must be the current
  * device.  Calls on one GPU share the array: two calls that may run at the same time (different streams) race; calls on
- * one stream, or otherwise ordered, are safe, and nothing needs clearing between them.  Allocates nothing. */
+ * one stream, or otherwise ordered, are safe, and nothing needs clearing between them.  Allocates nothing.  The first call on
+ * each device looks the array's address up (hipGetSymbolAddress, which may load the code object): make that call outside
+ * any graph capture; every later call only enqueues the two kernels. */
 #define VDA_GROUPNORM_STATIC_MAX_FRAMES 64
 int vda_groupnorm_static(const void* x, void* out, const float* weight, const float* bias, int frames, int hw, int C,
                          int groups, float eps, int dtype, void* stream);

@@ -269,6 +269,7 @@ def split3(x, out, rows, Cdim, ldx, Cp, relu=False, act=None, scale=1.0):
     _dev(x, out)
     if act is None:
         act = SPLIT_RELU if relu else SPLIT_NONE
+    _need("vda_split3", x=(x, (rows - 1) * ldx + (2 * Cdim if act == SPLIT_GEGLU else Cdim)), out=(out, rows * 3 * Cp))
     _check(lib().vda_split3(_ptr(x), _ptr(out), rows, Cdim, ldx, Cp, int(act), _type(out), float(scale), _stream()), "vda_split3")
 
 
@@ -276,8 +277,10 @@ def layernorm(x, out, weight, bias, rows, Cdim, eps, rows_per_group=None, in_gro
     _dev(x, out, weight, bias, pe)
     if rows_per_group is None:
         rows_per_group = in_group = rows
-    _need("vda_layernorm", x=(x, (rows // rows_per_group) * in_group * Cdim), out=(out, rows * Cdim), weight=(weight, Cdim),
-          bias=(bias, Cdim))
+    groups = -(-rows // rows_per_group)
+    last = (groups - 1) * in_group + in_skip + (rows - 1 - (groups - 1) * rows_per_group)       # the last input row read
+    _need("vda_layernorm", x=(x, (last + 1) * Cdim), out=(out, rows * Cdim), weight=(weight, Cdim), bias=(bias, Cdim),
+          pe=(pe, pe_T * Cdim))
     _check(lib().vda_layernorm(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), rows, Cdim, eps, rows_per_group, in_group,
                                in_skip, _ptr(pe), pe_hw, pe_T, _type(out), _stream()), "vda_layernorm")
 
@@ -298,7 +301,10 @@ def rowstats_finish(part, stat, rows, slots, eps):
 
 def groupnorm(x, out, weight, bias, work, frames, hw, Cdim, groups, eps):
     _dev(x, out, weight, bias, work)
-    _need("vda_groupnorm", x=(x, frames * hw * Cdim), out=(out, frames * hw * Cdim), weight=(weight, Cdim), bias=(bias, Cdim))
+    _need("vda_groupnorm", x=(x, frames * hw * Cdim), out=(out, frames * hw * Cdim), weight=(weight, Cdim), bias=(bias, Cdim),
+          work=(work, frames * GROUPNORM_MAX_SPLITS * groups * 2))
+    if work.dtype != torch.float64:
+        raise TypeError("vda_groupnorm: work is a float64 buffer")
     _check(lib().vda_groupnorm(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(work), frames, hw, Cdim, groups, eps,
                                _type(x), _stream()), "vda_groupnorm")
 
@@ -348,12 +354,17 @@ def temporal_attention(qkv, out, batch, T, hw, heads, hd, scale):
 
 def scale_shift_sums(pred, target, sums, n):
     _dev(pred, target, sums)
-    _need("vda_scale_shift_sums", pred=(pred, n), target=(target, n))
+    if sums.dtype != torch.float64:
+        raise TypeError("vda_scale_shift_sums: sums is a float64 buffer")
+    _need("vda_scale_shift_sums", pred=(pred, n), target=(target, n), sums=(sums, LSQ_SUMS_DOUBLES))
     _check(lib().vda_scale_shift_sums(_ptr(pred), _ptr(target), _ptr(sums), n, _stream()), "vda_scale_shift_sums")
 
 
 def solve_scale_shift(sums, ss):
     _dev(sums, ss)
+    if sums.dtype != torch.float64 or ss.dtype != torch.float32:
+        raise TypeError("vda_solve_scale_shift: float64 sums, float32 result")
+    _need("vda_solve_scale_shift", sums=(sums, 5), ss=(ss, 2))
     _check(lib().vda_solve_scale_shift(_ptr(sums), _ptr(ss), _stream()), "vda_solve_scale_shift")
 
 

@@ -29,7 +29,11 @@ MODEL_CONFIGS = {
 PATCH = 14
 POS_GRID = 37          # pos_embed is stored for a 518/14 = 37 x 37 grid (dinov2.py:407)
 TEMPORAL_HEADS = 8     # dpt_temporal.py:35
-CLAMPED_PROFILE_BIAS = 4.2    # output_conv2.2.bias of the "clamped" synthetic weight profile (the mixed-sign weights sum to about -3.8 on the hidden channels)
+# output_conv2.2.bias of the "clamped" synthetic weight profile: the mixed-sign weights sum to about -3.8 on the hidden
+# channels of the ViT-S head (median -4.3, deviation 1.35 at ViT-L width), so these put 20-45 % / about 30 % of the pixels at 0
+CLAMPED_PROFILE_BIAS = {"vits": 4.2, "vitl": 5.0}
+OUTLIER_POS_EMBED = (300.0, -500.0, 800.0, -1200.0, 2000.0, -3000.0)      # "outliers" profile: added to six channels of pos_embed
+OUTLIER_HEAD_BIAS = 5.5e4                                                 # ... and one channel of head.projects.2.bias
 
 
 def state_dict_spec(encoder="vitl", features=256, out_channels=(256, 512, 1024, 1024), num_frames=32):
@@ -144,9 +148,14 @@ def synth_state_dict(encoder="vitl", features=256, out_channels=(256, 512, 1024,
                  near the final ReLU clamp;
       "clamped"  mixed-sign mixing weights and a negative bias: a large share of the pixels is clamped to exactly 0
                  and the positive ones reach down to the clamp (what a trained checkpoint gives: sky = 0), so errors
-                 are measured where the 32 hidden channels cancel.
+                 are measured where the 32 hidden channels cancel;
+      "outliers" "smooth" plus the statistics trained vision transformers are known for and O(1) synthetic weights lack:
+                 six channels of the positional table at +-300 .. 3000 (a few residual-stream channels hundreds of times
+                 larger than the rest, in every token of every layer), LayerScale factors of up to 10 on four channels
+                 per block, and one head channel near 5.5e4 (a bias of ``projects.2``), close to the end of the IEEE-half
+                 range and far beyond what the fp32 mode's default operand scaling holds.
     """
-    if profile not in ("smooth", "clamped"):
+    if profile not in ("smooth", "clamped", "outliers"):
         raise ValueError(profile)
     out = OrderedDict()
     for key, (shape, kind) in state_dict_spec(encoder, features, out_channels, num_frames).items():
@@ -180,12 +189,22 @@ def synth_state_dict(encoder="vitl", features=256, out_channels=(256, 512, 1024,
         elif kind == "w_out2" and profile == "clamped":
             v = rs.standard_normal(n) * (1.0 / math.sqrt(n))
         elif kind == "b_out2" and profile == "clamped":
-            v = np.full(n, CLAMPED_PROFILE_BIAS)
+            v = np.full(n, CLAMPED_PROFILE_BIAS[encoder])
         elif kind == "w_out2":     # positive mixing weights keep the depth away from the ReLU clamp
             v = np.abs(rs.standard_normal(n)) * (1.0 / math.sqrt(n)) + 0.02
         elif kind == "b_out2":
             v = np.full(n, 0.25)
         else:
             raise KeyError(kind)
-        out[key] = np.asarray(v, dtype=np.float32).reshape(shape)
+        v = np.asarray(v, dtype=np.float32).reshape(shape)
+        if profile == "outliers":
+            pick = np.random.RandomState((zlib.crc32(("outliers/" + key).encode()) + 1000003 * seed) & 0xFFFFFFFF)
+            if key == "pretrained.pos_embed":
+                for c, a in zip(pick.choice(shape[2], 6, replace=False), OUTLIER_POS_EMBED):
+                    v[:, :, c] += a
+            elif kind == "ls":
+                v[pick.choice(n, 4, replace=False)] = pick.uniform(4.0, 10.0, 4).astype(np.float32)
+            elif key == "head.projects.2.bias":
+                v[pick.randint(n)] = OUTLIER_HEAD_BIAS
+        out[key] = v
     return out

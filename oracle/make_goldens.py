@@ -9,7 +9,7 @@ Weights come from the build's seeded generator (spec.synth_state_dict) and are l
 ``load_state_dict(strict=True)``; only inputs' seeds and the reference's outputs are stored.  While generating,
 the oracle restatement is checked against every reference output (fp32 vs fp32).
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py [--only-clamped | --only-lidar | --only-visualisation]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py [--only-clamped | --only-outliers | --only-lidar | --only-visualisation]
 """
 import json
 import os
@@ -123,6 +123,25 @@ def clamped_profile_goldens(RefVDA):
         np.savez_compressed(os.path.join(GOLD, "g5b_video_clamped.npz"), **g5)
 
 
+def outlier_profile_goldens(RefVDA):
+    """G4c: the forward pass with the "outliers" weight profile (a few residual-stream channels at +-300 .. 3000, LayerScale
+    factors up to 10, one head channel near 5.5e4): pins the behaviour under the activation ranges of trained checkpoints,
+    which the O(1) profiles never reach."""
+    cfg = spec.MODEL_CONFIGS["vits"]
+    sd = to_torch(spec.synth_state_dict(**cfg, seed=1, profile="outliers"))
+    ref = RefVDA(**cfg).eval()
+    ref.load_state_dict(sd, strict=True)
+    g = {}
+    with torch.no_grad():
+        for name, shape, seed in (("T32", (1, 32, 3, 70, 98), 41), ("B2T3", (2, 3, 3, 56, 42), 43)):
+            x = torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32))
+            out = ref(x).numpy()
+            check(f"G4c forward {name}", O.forward(sd, x, "vits").numpy(), out)
+            print(f"    depth range {out.min():.4g} .. {out.max():.4g}")
+            g[name] = out
+    np.savez_compressed(os.path.join(GOLD, "g4c_forward_outliers.npz"), **g)
+
+
 def lidar_cases():
     """Depth videos and LiDAR reference tables for the metric post-processing goldens (G8), seeded."""
     rs = np.random.RandomState(81)
@@ -196,6 +215,9 @@ def main():
     from video_depth_anything.video_depth import VideoDepthAnything as RefVDA
     if "--only-clamped" in sys.argv:      # add the G4b / G5b fixtures without rewriting the others
         clamped_profile_goldens(RefVDA)
+        return
+    if "--only-outliers" in sys.argv:
+        outlier_profile_goldens(RefVDA)
         return
     if "--only-lidar" in sys.argv:
         lidar_goldens()
@@ -357,6 +379,7 @@ def main():
         g7["fusion"] = out
         np.savez_compressed(os.path.join(GOLD, "g7_vitl_width.npz"), **g7)
     clamped_profile_goldens(RefVDA)
+    outlier_profile_goldens(RefVDA)
     lidar_goldens()
     visualisation_goldens()
     print("goldens written to", GOLD)

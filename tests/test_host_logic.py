@@ -139,6 +139,53 @@ def test_wrappers_refuse_extents_beyond_the_tensor_storage():
         hip._need("vda_attention", qkv=(q, 2 * 5 * 3 * 3 * 64))
 
 
+def test_every_wrapper_with_scratch_or_table_arguments_checks_them(monkeypatch):
+    """The wrappers themselves, with the library replaced by a recorder (nothing is launched): workspaces, result buffers and
+    tables that are too small are refused before the call reaches the C ABI."""
+    calls = []
+
+    class Recorder:
+        def __getattr__(self, name):
+            return lambda *a: calls.append(name) or 0
+
+    monkeypatch.setattr(hip, "lib", lambda: Recorder())
+    monkeypatch.setattr(hip, "_dev", lambda *ts: None)
+    monkeypatch.setattr(hip, "_stream", lambda: None)
+    f32, f64, f16 = torch.float32, torch.float64, torch.float16
+    x = torch.zeros(4 * 6 * 64, dtype=f16)
+    w = torch.zeros(64)
+    ok_work = torch.zeros(4 * hip.GROUPNORM_MAX_SPLITS * 32 * 2, dtype=f64)
+    hip.groupnorm(x, x.clone(), w, w, ok_work, 4, 6, 64, 32, 1e-6)
+    with pytest.raises(ValueError, match="work"):
+        hip.groupnorm(x, x.clone(), w, w, torch.zeros(ok_work.numel() - 1, dtype=f64), 4, 6, 64, 32, 1e-6)
+    with pytest.raises(TypeError):
+        hip.groupnorm(x, x.clone(), w, w, ok_work.float(), 4, 6, 64, 32, 1e-6)
+    a = torch.zeros(5, 128)
+    hip.split3(a, torch.zeros(5, 3 * 128, dtype=f16), 5, 128, 128, 128)
+    hip.split3(a, torch.zeros(5, 3 * 64, dtype=f16), 5, 64, 128, 64, act=hip.SPLIT_GEGLU)
+    with pytest.raises(ValueError, match="out"):
+        hip.split3(a, torch.zeros(5, 3 * 128 - 1, dtype=f16), 5, 128, 128, 128)
+    with pytest.raises(ValueError, match="x holds"):
+        hip.split3(torch.zeros(5, 100), torch.zeros(5, 3 * 128, dtype=f16), 5, 128, 128, 128)
+    with pytest.raises(ValueError, match="x holds"):
+        hip.split3(a, torch.zeros(5, 3 * 128, dtype=f16), 5, 128, 128, 128, act=hip.SPLIT_GEGLU)       # gated rows are 2C wide
+    p = torch.zeros(100)
+    sums = torch.zeros(hip.LSQ_SUMS_DOUBLES, dtype=f64)
+    hip.scale_shift_sums(p, p, sums, 100)
+    with pytest.raises(ValueError, match="sums"):
+        hip.scale_shift_sums(p, p, torch.zeros(5, dtype=f64), 100)
+    hip.solve_scale_shift(sums, torch.zeros(2))
+    with pytest.raises(ValueError, match="ss"):
+        hip.solve_scale_shift(sums, torch.zeros(1))
+    rows = torch.zeros(2 * 5 * 64)                       # two groups of five input rows, the first of each skipped
+    hip.layernorm(rows, torch.zeros(8 * 64, dtype=f16), w, w, 8, 64, 1e-6, rows_per_group=4, in_group=5, in_skip=1)
+    with pytest.raises(ValueError, match="x holds"):
+        hip.layernorm(torch.zeros(2 * 5 * 64 - 1), torch.zeros(8 * 64, dtype=f16), w, w, 8, 64, 1e-6, rows_per_group=4, in_group=5, in_skip=1)
+    with pytest.raises(ValueError, match="pe"):
+        hip.layernorm(rows, torch.zeros(10 * 64, dtype=f16), w, w, 10, 64, 1e-6, pe=torch.zeros(3 * 64), pe_hw=1, pe_T=4)
+    assert calls.count("vda_groupnorm") == 1 and calls.count("vda_split3") == 2 and calls.count("vda_layernorm") == 1
+
+
 def test_packed_weights_fold_the_encoder_layernorms_into_qkv_and_fc1():
     """The folded form the GEMM epilogues evaluate, rstd (x W'^T - mean colsum(W')) + b', is LayerNorm(x) W^T + b for the same
     rows x (block.py:84,87 -> attention.py:51, mlp.py:36), up to the one rounding of W' = W diag(ln_weight) to bf16; and the

@@ -441,6 +441,31 @@ def test_vitl_fp32_mode_518_against_oracle_on_device(vitl):
     assert worst <= FP32_MODE_MAX_REL and ar <= FP32_MODE_MAX_REL
 
 
+@pytest.mark.parametrize("fp32", [True, False])
+def test_vitl_518_on_clamped_depth_maps_against_oracle_on_device(vitl, fp32):
+    """The clamped weight profile at the flagship width and frame size (ViT-L, 24 layers, F = 256, 1x8x3x518x518): about a
+    third of the pixels end at exactly 0 and the positive ones reach down to the clamp.  The fp32 storage mode meets the stated
+    bounds there; the 16-bit mode is held to its absolute-error bounds (see check_clamped)."""
+    m, sd_dev = vitl
+    tail = {k: torch.from_numpy(v) for k, v in spec.synth_state_dict(**spec.MODEL_CONFIGS["vitl"], seed=1, profile="clamped",
+                                                                       only=["head.scratch.output_conv2.2."]).items()}
+    assert len(tail) == 2
+    smooth = {k: m.state_dict()[k].clone() for k in tail}
+    x = torch.from_numpy(np.random.RandomState(2).standard_normal((1, 8, 3, 518, 518)).astype(np.float32)).cuda()
+    try:
+        m.load_state_dict({**m.state_dict(), **tail}, strict=True)
+        m.precision = "fp32" if fp32 else "half"
+        got = m(x).cpu().numpy()
+    finally:
+        m.precision = "half"
+        m.load_state_dict({**m.state_dict(), **smooth}, strict=True)
+    want = oracle_on_device({**sd_dev, **{k: v.cuda() for k, v in tail.items()}}, x, "vitl")
+    for t in range(0, 8, 4):
+        check_clamped(f"vitl 518 clamped, frames {t}..{t + 3}, fp32={fp32}", got[0, t:t + 4], want[0, t:t + 4], fp32)
+    if fp32:
+        assert max(O.max_rel_err(got[0, t], want[0, t]) for t in range(8)) <= MAX_REL
+
+
 def test_vitl_wide_frame_518x924_against_oracle_on_device(vitl):
     """The 16:9 network size of 720p / 1080p sources (37 x 66 patches: resampled positional table, 2443 tokens, every
     GEMM with M and attention with a token count that are not multiples of the tiles)."""
@@ -579,6 +604,23 @@ def test_vitl_720p_video_sharded_over_two_ranks(vitl, dashcam_frames, tmp_path):
         assert got.shape == want.shape == (34, 720, 1280)
         assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), r
         assert owned.sum() == (24 if r == 0 else 10)
+
+
+def test_vits_480x854_video_in_fp32_mode_against_oracle_on_device(vits):
+    """The reference's own CPU-runnable configuration (run.py on a 480 x 854 clip, ViT-S, input_size 518, fp32): 34 frames ->
+    device bicubic resize to 518 x 924 (37 x 66 patches) -> two windows in the fp32 storage mode -> depth at 480 x 854."""
+    model, sd = vits
+    sd_dev = {k: v.cuda() for k, v in sd.items()}
+    frames = synth_frames(34, 480, 854, 1234)
+    assert O.network_size(480, 854, 518) == (518, 924)
+    got, fps = model.infer_video_depth(frames, 24, input_size=518, device="cuda", fp32=True, batch_size=32)
+    assert fps == 24 and got.shape == (34, 480, 854) and got.dtype == np.float32
+    want = O.infer_video_depth(None, list(frames), "vits", batch_size=32, input_size=518,
+                               forward_fn=lambda inp: O.forward(sd_dev, inp.cuda(), "vits"))
+    worst = max(O.max_rel_err(got[t], want[t]) for t in range(34))
+    ar = O.abs_rel(got, want)
+    print(f"vits 480x854 video in fp32 mode, 2 windows: worst per-frame max_rel={worst:.3e} abs_rel={ar:.3e}")
+    assert worst <= MAX_REL and ar <= ABS_REL
 
 
 def test_clamp_input_size_on_gpu_reproduces_the_reference_gpu_default(vits):
