@@ -117,6 +117,17 @@ typedef struct VdaGemmArgs {
                                rstd[m] * (acc[m][n] - mean[m] * w_colsum[n]) before bias / activation.  A_LINEAR, EPI_PLAIN,
                                no residual                                                                              */
     const float* w_colsum;  /* [N], required with row_stat                                                            */
+    /* fp32 mode: the output written directly as the next product's 16-bit operand (what vda_split3 would make of the fp32
+       result), so that neither the fp32 matrix nor a split pass over it exists. */
+    int   split_out;      /* 0 = off.  2 or 3: `out` is ab_type [M][ldc], ldc >= split_out * N, and receives the pieces of
+                             split_scale * v (v = the epilogue's result) in segments of N columns: [hi | lo] (2: the form
+                             vda_attention_pairs reads) or [hi | lo | hi] (3: the A operand of vda_gemm, see vda_split3).
+                             out_type is ignored.  With act VDA_ACT_GELU the exact erf form is evaluated (as VDA_SPLIT_GELU).
+                             Needs A_LINEAR, EPI_PLAIN, no gamma, no residual, N % 64 == 0, 16-byte aligned out, ldc % 8 == 0;
+                             else VDA_ESHAPE                                                                           */
+    float split_scale;    /* power of two > 0 (see vda_split3's `scale`)                                                */
+    int*  sat_flag;       /* NULL or one int in device memory that is set to 1 when a scaled value leaves the IEEE-half range
+                             (|split_scale * v| > 65504; the piece saturates); never cleared here                        */
 } VdaGemmArgs;
 
 int vda_gemm(const VdaGemmArgs* args, void* stream);
@@ -139,17 +150,27 @@ int vda_gemm_kernel_choice(const VdaGemmArgs* args);
 #define VDA_ATTENTION_Q_SCALE 0.18033688011112042   /* log2(e) / 8 */
 int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, int dtype, void* stream);
 
+/* The fp32 mode's attention on operands that are already split: qkv2 is IEEE half [frames][n_tok][2][3*heads*64], per token
+ * the hi pieces of `scale` * [q | k | v] followed by the lo pieces (VdaGemmArgs.split_out = 2 of the fused QKV projection);
+ * out3 is IEEE half [frames][n_tok][3][heads*64] = [hi | lo | hi] of `scale` * output: the A operand of the output projection.
+ * Same arithmetic as vda_attention with dtype VDA_T_F32 (three-term products, fp32 softmax state), but K and V tiles go
+ * global -> LDS without passing through registers and are not split again by every query block.  `scale` is the power of
+ * two the producer used (q, k and v share it). */
+int vda_attention_pairs(const void* qkv2, void* out3, int frames, int n_tok, int heads, float scale, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Row LayerNorm (biased variance, eps inside the sqrt): fp32 rows in, rows of out_type (BF16, F16 or F32) out.
  * Output row r reads input row (r / rows_per_group) * in_group + in_skip + r % rows_per_group, which drops the class
  * token when taking the encoder taps (dinov2.py:310-312); with rows_per_group == in_group and in_skip == 0 it is the
  * identity map.  If pe != NULL, pe[((r / pe_hw) % pe_T)][c] (fp32 [pe_T][C]) is added after the affine step: the
  * temporal position table of motion_module.py:196-197 applied to rows ordered (frame, position).
+ * split_scale != 0 (fp32 mode; out_type BF16 or F16, C % 64 == 0): the output rows are [rows][3*C], the [hi | lo | hi]
+ * pieces of split_scale * y that vda_split3 would make of the fp32 result y; sat_flag as in VdaGemmArgs (may be NULL).
  * Replaces block.py:84,87 (norm1/norm2), dinov2.py:310, motion_module.py:166,174.
  * ------------------------------------------------------------------------------------------------------------- */
 int vda_layernorm(const float* x, void* out, const float* weight, const float* bias, int rows, int C, float eps,
                   int rows_per_group, int in_group, int in_skip, const float* pe, int pe_hw, int pe_T, int out_type,
-                  void* stream);
+                  float split_scale, int* sat_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Row statistics for a LayerNorm that is folded into the product that follows it (VdaGemmArgs.row_stat; block.py:84,87).
@@ -219,10 +240,12 @@ int vda_assemble_tokens(const float* tok, const float* cls, const float* pos, fl
  *                    projection packed for VDA_EPI_GEGLU, run with a plain epilogue); v = value * GELU(gate)
  *                    (motion_module/attention.py:382-384); C % 16 == 0, ldx >= 2C.
  * For an NHWC image rows = pixels and the result is an image with 3*Cp channels: the CONV3 operand for weights packed
- * [Cout][9][hi | hi | lo].  No counterpart in the reference (its fp32 path multiplies in fp32).
+ * [Cout][9][hi | hi | lo].  sat_flag: NULL, or one int in device memory that is set to 1 when |scale * v| > 65504 for some
+ * value (IEEE-half pieces only; the piece saturates).  No counterpart in the reference (its fp32 path multiplies in fp32).
  * ------------------------------------------------------------------------------------------------------------- */
 enum { VDA_SPLIT_NONE = 0, VDA_SPLIT_RELU = 1, VDA_SPLIT_GELU = 2, VDA_SPLIT_GEGLU = 3 };
-int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int act, int out_type, float scale, void* stream);
+int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int act, int out_type, float scale, int* sat_flag,
+               void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Frame preprocessing: uint8 RGB frames [frames][h0][w0][3] -> fp32 [frames][3][H][W]: x/255, bicubic resize with

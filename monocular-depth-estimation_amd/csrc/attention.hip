@@ -387,7 +387,190 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restr
     }
 }
 
+
+// fp32 storage mode on operands that arrive split.  qkv2: per token the IEEE-half hi pieces of scale * [q | k | v] followed by
+// the lo pieces (the QKV projection writes them, VdaGemmArgs.split_out = 2); out3: per token [hi | lo | hi] of scale * output, the
+// operand of the output projection.  Structure of attn_kernel<1>: the four 8 KiB images of a 64-key tile (K hi, K lo, V hi,
+// V lo) are copied global -> LDS by global_load_lds into a double buffer, the scores are accumulated onto minus the running
+// maximum and every product is the three-term sum hi*hi + lo*hi + hi*lo.  Scores carry the factor scale^2 (both operands are
+// scaled), so the running maximum is kept in those units and a probability is exp2(s / scale^2 + log2 P_SCALE): one fused
+// multiply-add in front of the hardware exponential, whose result is already the scaled probability that is split.
+__global__ __launch_bounds__(256, 2) void attn_pairs_kernel(const f16* __restrict__ qkv, f16* __restrict__ out, int n_tok, int heads,
+                                                            int q_blocks, float s2) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 32768];      // per buffer: K hi, K lo, V hi, V lo (8 KiB each)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7;
+    const int per = nwg >> 3, rem = nwg & 7;
+    const int wg = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (blockIdx.x >> 3);
+    const int fh = wg / q_blocks, qb = wg - fh * q_blocks;
+    const int frame = fh / heads, head = fh - frame * heads;
+    const int D = heads * 64, lo_off = 3 * D, ld = 6 * D;
+    const f16* base = qkv + (size_t)frame * n_tok * ld + head * 64;
+    const int q0 = qb * 128 + wave * 32;
+    const float inv_s2 = 1.0f / s2;
+    constexpr float LOG2_P_SCALE = 8.f;                                // P_SCALE = 256
+
+    f16x8 qhi[4], qlo[4];
+    {
+        const f16* qrow = base + (size_t)min(q0 + r, n_tok - 1) * ld + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qhi[ks] = *reinterpret_cast<const f16x8*>(qrow + 16 * ks);
+            qlo[ks] = *reinterpret_cast<const f16x8*>(qrow + lo_off + 16 * ks);
+        }
+    }
+
+    const int srow = tid >> 3, sc = tid & 7;
+    const f16* kbase = base + D;
+    const f16* vbase = base + 2 * D;
+    auto stage_tile = [&](int kt, int buf) {
+        char* b0 = smem + buf * 32768;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = i * 32 + srow;
+            const size_t g = (size_t)min(kt * 64 + row, n_tok - 1) * ld;
+            const int kc = (sc ^ ((row >> 1) & 7)) << 3, vc = (sc ^ (((row >> 1) & 1) << 2)) << 3;
+            glds16(kbase + g + kc, b0 + i * 4096 + wave * 1024);
+            glds16(kbase + g + lo_off + kc, b0 + 8192 + i * 4096 + wave * 1024);
+            glds16(vbase + g + vc, b0 + 16384 + i * 4096 + wave * 1024);
+            glds16(vbase + g + lo_off + vc, b0 + 24576 + i * 4096 + wave * 1024);
+        }
+    };
+
+    f32x16 o[2], negm;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; negm[i] = 0.f; }
+    float m_run = 0.f, l_run = 0.f;          // the running maximum in score units times scale^2; the sum of P_SCALE * p
+
+    const int nkt = (n_tok + 63) / 64;
+    stage_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qhi[ks]), "+v"(qlo[ks]));      // landed: see attn_kernel
+
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int tcol = 16 * ((lane >> 4) & 1) + 4 * tp;
+    const float defer = DEFER * s2;
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) stage_tile(kt + 1, cur ^ 1);
+        const char* kh = smem + cur * 32768;
+        const char* kl = kh + 8192;
+        const char* vh = kh + 16384;
+        const char* vl = kh + 24576;
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = tile_off(32 * kbk + r, 2 * ks + h);
+                const f16x8 khi = *reinterpret_cast<const f16x8*>(kh + off);
+                const f16x8 klo = *reinterpret_cast<const f16x8*>(kl + off);
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qhi[ks], ks == 0 ? negm : s[kbk], 0, 0, 0);
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qlo[ks], s[kbk], 0, 0, 0);
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qhi[ks], s[kbk], 0, 0, 0);
+            }
+        }
+        if (kt == nkt - 1) {
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 64 + 32 * kbk + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= n_tok) s[kbk][i] = -INFINITY;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
+        if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > defer) != 0) {
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+            const float alpha = kt == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta * inv_s2);
+            m_run += delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                o[0][i] *= alpha; o[1][i] *= alpha;
+                s[0][i] -= delta; s[1][i] -= delta;
+                negm[i] = -m_run;
+            }
+        }
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+        f16x8 ph[2][2], pl[2][2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kbk][i], inv_s2, LOG2_P_SCALE));     // P_SCALE * p <= 2^14
+                ps[i & 3] += pv;
+                const f16 x = (f16)pv;
+                ph[kbk][i >> 3][i & 7] = x;
+                pl[kbk][i >> 3][i & 7] = (f16)(pv - (float)x);
+            }
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int s2i = 0; s2i < 2; ++s2i) {
+                    const int k0 = 32 * kbk + 16 * s2i + 4 * h + tq;
+                    const int o0 = v_off(k0, 32 * db + tcol), o1 = v_off(k0 + 8, 32 * db + tcol);
+                    const f16x4 a0 = read_tr_f16(vh + o0);
+                    const f16x4 a1 = read_tr_f16(vh + o1);
+                    const f16x4 b0 = read_tr_f16(vl + o0);
+                    const f16x4 b1 = read_tr_f16(vl + o1);
+                    const f16x8 vhi = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    const f16x8 vlo = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, ph[kbk][s2i], o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, pl[kbk][s2i], o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, ph[kbk][s2i], o[db], 0, 0, 0);
+                }
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's copies of the next tile have landed
+        __syncthreads();
+    }
+
+    // o = (scale * v) (P_SCALE * p) summed; l_run = sum of P_SCALE * p: their ratio is scale * output, the value to split
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + r;
+    if (q < n_tok) {
+        f16* orow = out + ((size_t)frame * n_tok + q) * (3 * D) + head * 64 + 4 * h;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
+                f16x4 hi, lo;
+                split4<f16>(v, hi, lo);
+                f16* dst = orow + 32 * db + 8 * g;
+                *reinterpret_cast<f16x4*>(dst) = hi;
+                *reinterpret_cast<f16x4*>(dst + D) = lo;
+                *reinterpret_cast<f16x4*>(dst + 2 * D) = hi;
+            }
+    }
+}
+
 }  // namespace
+
+extern "C" int vda_attention_pairs(const void* qkv2, void* out3, int frames, int n_tok, int heads, float scale, void* stream) {
+    if (!qkv2 || !out3 || frames <= 0 || n_tok <= 0 || heads <= 0 || !(scale > 0.f)) return VDA_EINVAL;
+    if ((((uintptr_t)qkv2 | (uintptr_t)out3) & 15) != 0) return VDA_ESHAPE;
+    const int qb = (n_tok + 127) / 128;
+    if ((long)frames * heads * qb > 0x7fffffffL) return VDA_ESHAPE;
+    hipLaunchKernelGGL(attn_pairs_kernel, dim3(frames * heads * qb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const f16*>(qkv2), reinterpret_cast<f16*>(out3), n_tok, heads, qb, scale * scale);
+    return hip_rc(hipGetLastError());
+}
 
 extern "C" int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, int dtype, void* stream) {
     if (!qkv || !out || frames <= 0 || n_tok <= 0 || heads <= 0) return VDA_EINVAL;

@@ -93,4 +93,26 @@ __device__ __forceinline__ void split_f16(float v, f16& hi, f16& lo) {
 __device__ __forceinline__ void split_any(float v, bf16& hi, bf16& lo) { split_bf16(v, hi, lo); }
 __device__ __forceinline__ void split_any(float v, f16& hi, f16& lo) { split_f16(v, hi, lo); }
 
+// Range guard of the IEEE-half pieces: a scaled value beyond the largest finite half saturates in split_f16; the caller's flag
+// word is then set (a plain vector store of the same 1 from every lane that sees one).  `v` holds scaled values.
+constexpr float F16_MAX = 65504.f;
+__device__ __forceinline__ void note_saturation(int* flag, f32x4 v) {
+    const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    if (flag && m > F16_MAX) *reinterpret_cast<volatile int*>(flag) = 1;
+}
+__device__ __forceinline__ void note_saturation_as(int* flag, f32x4 v, f16) { note_saturation(flag, v); }
+__device__ __forceinline__ void note_saturation_as(int*, f32x4, bf16) {}          // bf16 pieces have fp32's range
+
+// The [hi | lo | ...] pieces of four scaled values, as two 8-byte vectors.
+template <typename T>
+__device__ __forceinline__ void split4(f32x4 v, typename Vec<T>::v4& hi, typename Vec<T>::v4& lo) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        T h, l;
+        split_any(v[k], h, l);
+        hi[k] = h;
+        lo[k] = l;
+    }
+}
+
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }

@@ -168,6 +168,7 @@ int launch_t(const VdaGemmArgs& a, hipStream_t s) {
         VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_RES) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_RES32) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_GEGLU)
         VDA_CASE(VDA_A_LINEAR, EPI_SPEC_F32) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_CONVT)
         VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_LN) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_OWN_GELU_LN) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_F32_RES32_EMIT)
+        VDA_CASE(VDA_A_LINEAR, EPI_SPEC_SPLIT) VDA_CASE(VDA_A_LINEAR, EPI_SPEC_SPLIT_GELU)
         default: return launch_k<BM, BN, WM, WN, VDA_A_LINEAR, EPI_SPEC_GENERAL, T>(a, s);
     }
 #undef VDA_CASE
@@ -215,8 +216,16 @@ int check_args(const VdaGemmArgs* args) {
         return VDA_EINVAL;
     }
     if (a.out_type != VDA_T_F32 && a.out_type != VDA_T_BF16 && a.out_type != VDA_T_F16) return VDA_EINVAL;
-    // the epilogue's GELU is accurate to 16-bit storage only; fp32 callers apply the exact one in vda_split3
-    if ((a.act == VDA_ACT_GELU || a.epi == VDA_EPI_GEGLU) && a.out_type == VDA_T_F32) return VDA_ESHAPE;
+    // the epilogue's GELU is accurate to 16-bit storage only; fp32 callers apply the exact one in vda_split3 or ask for a
+    // split output, whose GELU is the exact form
+    if ((a.act == VDA_ACT_GELU || a.epi == VDA_EPI_GEGLU) && a.out_type == VDA_T_F32 && !a.split_out) return VDA_ESHAPE;
+    if (a.split_out) {
+        if (a.split_out != 2 && a.split_out != 3) return VDA_EINVAL;
+        if (!(a.split_scale > 0.f)) return VDA_EINVAL;
+        if (a.a_mode != VDA_A_LINEAR || a.epi != VDA_EPI_PLAIN || a.gamma || a.resid_type != VDA_T_NONE || a.row_stat || a.out16) return VDA_ESHAPE;
+        if (a.act == VDA_ACT_RELU) return VDA_ESHAPE;
+        if (a.N % 64 != 0 || a.ldc % 8 != 0 || a.ldc < a.split_out * a.N || ((uintptr_t)a.out & 15) != 0) return VDA_ESHAPE;
+    }
     if (a.ab_type != VDA_T_BF16 && a.ab_type != VDA_T_F16) return VDA_EINVAL;
     if (a.tile_cfg < 0 || a.tile_cfg > 3) return VDA_EINVAL;
     // folded LayerNorm: consumer side (row_stat / w_colsum) and producer side (out16 / row_part)

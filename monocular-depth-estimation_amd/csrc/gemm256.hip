@@ -345,6 +345,7 @@ int launch_t(const VdaGemmArgs& a, hipStream_t s) {
             VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_F32) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_CONVT)
             VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN_LN) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_OWN_GELU_LN)
             VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_F32_RES32_EMIT)
+            VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_SPLIT) VDA_CASE256(VDA_A_LINEAR, false, EPI_SPEC_SPLIT_GELU)
             default: VDA_LAUNCH256(VDA_A_LINEAR, false, EPI_SPEC_GENERAL);
         }
     }

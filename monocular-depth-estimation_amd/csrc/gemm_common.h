@@ -175,7 +175,10 @@ template <int TM, int TN, bool RS_PRE = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq,
                                                      char* stage, const f32x4 (*pre)[TN] = nullptr, const f32x2* rs_pre = nullptr) {
     const int lane = threadIdx.x & 63, frow = lane & 15;
-    const int esz = p.out_type == VDA_T_F32 ? 4 : 2;
+    // split output (VdaGemmArgs.split_out): the block is staged in fp32 and each 16-byte piece is split while it is copied out
+    const bool split = p.split_out != 0;
+    const int st_type = split ? VDA_T_F32 : p.out_type;       // element type inside the staging area
+    const int esz = st_type == VDA_T_F32 ? 4 : 2;
     const bool geglu = p.epi == VDA_EPI_GEGLU;
     const int cols = geglu ? TN * 8 : TN * 16;               // output columns of the wave's block
     const int row_bytes = cols * esz;
@@ -214,6 +217,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
         row_part = kernarg_field_now<float*>(offsetof(VdaGemmArgs, row_part));
         ld16 = (unsigned)kernarg_field_now<int>(offsetof(VdaGemmArgs, ld16));
     }
+    float split_scale = 1.f;
+    int* sat_flag = nullptr;
+    if (split) {
+        split_scale = kernarg_field_now<float>(offsetof(VdaGemmArgs, split_scale));
+        sat_flag = kernarg_field_now<int*>(offsetof(VdaGemmArgs, sat_flag));
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = mrow0 + i * 16;                          // this lane's row of the m-tile
@@ -235,7 +244,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
                 for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= acc[i][j][r] + bias[j][r];
-                store4(srow, p.out_type, (j / 2) * 16 + fq * 4, v);
+                store4(srow, st_type, (j / 2) * 16 + fq * 4, v);
             }
         } else {
 #pragma unroll
@@ -248,8 +257,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
                     v = acc[i][j] + bias[j];
                 }
                 if (p.act == VDA_ACT_GELU) {
+                    // (split output: the value keeps fp32 precision, so the erf form good to 1.5e-7, not the 16-bit fit)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = split ? gelu_erf(v[r]) : gelu_poly(v[r]);
                 } else if (p.act == VDA_ACT_RELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -261,7 +271,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
                     if (p.resid_type != VDA_T_NONE) v += load4(p.resid, p.resid_type, (size_t)m * p.ldr + n);
                     if (p.resid2) v += load4(p.resid2, p.resid_type, (size_t)m * p.ldr2 + n);
                 }
-                store4(srow, p.out_type, j * 16 + fq * 4, v);
+                store4(srow, st_type, j * 16 + fq * 4, v);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's LDS writes are done before any of its lanes reads
@@ -272,6 +282,29 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
                 const int mm = mbase + row;
                 const int col = (c_chunk << 4) / esz;          // first output column of this lane's chunk
                 const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * rs + (c_chunk << 4));
+                if (split) {
+                    // four fp32 values -> their scaled 16-bit pieces, stored at the same columns of each segment of the row
+                    if (mm < p.M && out_n0 + col < n_out) {
+                        const f32x4 f = __builtin_bit_cast(f32x4, v) * split_scale;
+                        char* dst = reinterpret_cast<char*>(p.out) + ((size_t)mm * p.ldc + out_n0 + col) * 2;
+                        const size_t seg = (size_t)p.N * 2;
+                        if (p.ab_type == VDA_T_F16) {
+                            note_saturation(sat_flag, f);
+                            f16x4 hi, lo;
+                            split4<f16>(f, hi, lo);
+                            __builtin_nontemporal_store(hi, reinterpret_cast<f16x4*>(dst));
+                            __builtin_nontemporal_store(lo, reinterpret_cast<f16x4*>(dst + seg));
+                            if (p.split_out == 3) __builtin_nontemporal_store(hi, reinterpret_cast<f16x4*>(dst + 2 * seg));
+                        } else {
+                            bf16x4 hi, lo;
+                            split4<bf16>(f, hi, lo);
+                            __builtin_nontemporal_store(hi, reinterpret_cast<bf16x4*>(dst));
+                            __builtin_nontemporal_store(lo, reinterpret_cast<bf16x4*>(dst + seg));
+                            if (p.split_out == 3) __builtin_nontemporal_store(hi, reinterpret_cast<bf16x4*>(dst + 2 * seg));
+                        }
+                    }
+                    continue;
+                }
                 if (mm < p.M && out_n0 + col < n_out) {
                     size_t pix = mm;
                     if (convt) {
@@ -301,7 +334,7 @@ template <int TM, int TN, bool RS_PRE = false>
 __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int ncol0, int fq,
                                               char* stage = nullptr, const f32x4 (*pre)[TN] = nullptr, const f32x2* rs_pre = nullptr) {
     if (stage && (p.epi == VDA_EPI_PLAIN || p.epi == VDA_EPI_GEGLU || p.epi == VDA_EPI_CONVT)) {
-        const int esz = p.out_type == VDA_T_F32 ? 4 : 2;
+        const int esz = (p.out_type == VDA_T_F32 || p.split_out) ? 4 : 2;
         const int n_out = p.epi == VDA_EPI_GEGLU ? p.N / 2 : p.N;
         const int cols = p.epi == VDA_EPI_GEGLU ? TN * 8 : TN * 16;
         // 16-byte row alignment of the output, whole chunks inside N, and at most 64 chunks per 16-row block row set;
@@ -312,6 +345,7 @@ __device__ __forceinline__ void gemm_epilogue(const VdaGemmArgs& p, f32x4 (&acc)
             return;
         }
     }
+    if (p.split_out) return;      // vda_gemm only accepts split outputs in shapes that take the staged form above
     if (p.epi == VDA_EPI_DOT) {
         float part[TM];
 #pragma unroll
@@ -442,13 +476,18 @@ enum {
     EPI_SPEC_CONVT = 11,         // transposed-convolution scatter, own-type output, bias
     EPI_SPEC_OWN_LN = 12,        // EPI_SPEC_OWN on rows whose LayerNorm is folded in (row_stat / w_colsum)
     EPI_SPEC_OWN_GELU_LN = 13,   // EPI_SPEC_OWN_GELU, likewise
-    EPI_SPEC_F32_RES32_EMIT = 14 // EPI_SPEC_F32_RES32 that also emits the rounded rows and their partial sums (out16 / row_part)
+    EPI_SPEC_F32_RES32_EMIT = 14,// EPI_SPEC_F32_RES32 that also emits the rounded rows and their partial sums (out16 / row_part)
+    EPI_SPEC_SPLIT = 15,         // plain, bias, output split into 16-bit pieces (split_out)
+    EPI_SPEC_SPLIT_GELU = 16     // ... after the exact GELU
 };
 
 // the specialisation that describes this call exactly, or EPI_SPEC_GENERAL
 inline int epi_spec_of(const VdaGemmArgs& a) {
     const int own = a.ab_type == VDA_T_F16 ? VDA_T_F16 : VDA_T_BF16;
     if (a.gamma) return EPI_SPEC_GENERAL;
+    if (a.split_out)
+        return a.resid_type != VDA_T_NONE || a.row_stat || a.out16 ? EPI_SPEC_GENERAL
+               : a.act == VDA_ACT_NONE ? EPI_SPEC_SPLIT : a.act == VDA_ACT_GELU ? EPI_SPEC_SPLIT_GELU : EPI_SPEC_GENERAL;
     if (a.row_stat)
         return a.out_type == own && a.resid_type == VDA_T_NONE && !a.out16
                    ? (a.act == VDA_ACT_NONE ? EPI_SPEC_OWN_LN : a.act == VDA_ACT_GELU ? EPI_SPEC_OWN_GELU_LN : EPI_SPEC_GENERAL)
@@ -482,7 +521,10 @@ __device__ __forceinline__ VdaGemmArgs epi_spec_args(const VdaGemmArgs& p) {
     VdaGemmArgs q = p;
     q.gamma = nullptr;
     q.epi = SPEC == EPI_SPEC_GEGLU ? VDA_EPI_GEGLU : SPEC == EPI_SPEC_DOT ? VDA_EPI_DOT : SPEC == EPI_SPEC_CONVT ? VDA_EPI_CONVT : VDA_EPI_PLAIN;
-    q.act = (SPEC == EPI_SPEC_OWN_GELU || SPEC == EPI_SPEC_OWN_GELU_LN) ? VDA_ACT_GELU : SPEC == EPI_SPEC_OWN_RELU ? VDA_ACT_RELU : VDA_ACT_NONE;
+    q.act = (SPEC == EPI_SPEC_OWN_GELU || SPEC == EPI_SPEC_OWN_GELU_LN || SPEC == EPI_SPEC_SPLIT_GELU) ? VDA_ACT_GELU
+            : SPEC == EPI_SPEC_OWN_RELU ? VDA_ACT_RELU : VDA_ACT_NONE;
+    if (SPEC != EPI_SPEC_SPLIT && SPEC != EPI_SPEC_SPLIT_GELU) q.split_out = 0;
+    else __builtin_assume(q.split_out != 0);
     constexpr bool res32 = SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_F32_RES32_EMIT;
     q.out_type = (res32 || SPEC == EPI_SPEC_F32 || SPEC == EPI_SPEC_DOT) ? VDA_T_F32 : own;
     q.ab_type = own;

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
 // One workgroup per 4 rows; 32-bit index arithmetic inside a row.
 template <typename T>
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, T* __restrict__ out, long rows, int C,
-                                                     int ldx, int Cp, int act, float scale) {
+                                                     int ldx, int Cp, int act, float scale, int* sat_flag) {
     const long row0 = (long)blockIdx.x * 4;
     const int cv = Cp / 4;
     for (int i = threadIdx.x; i < 4 * cv; i += 256) {
@@ -193,11 +193,10 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
             float f = v[k];
             if (act == VDA_SPLIT_RELU) f = fmaxf(f, 0.f);
             if (act == VDA_SPLIT_GELU) f = gelu_erf(f);
-            T h, l;
-            split_any(f * scale, h, l);
-            hi[k] = h;
-            lo[k] = l;
+            v[k] = f * scale;
         }
+        note_saturation_as(sat_flag, v, T{});
+        split4<T>(v, hi, lo);
         T* o = out + row * (3L * Cp) + c;
         *reinterpret_cast<typename Vec<T>::v4*>(o) = hi;
         *reinterpret_cast<typename Vec<T>::v4*>(o + Cp) = lo;
@@ -259,7 +258,7 @@ extern "C" int vda_im2col_patch14(const float* x, void* out, int frames, int H, 
 }
 
 extern "C" int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int act, int out_type, float scale,
-                          void* stream) {
+                          int* sat_flag, void* stream) {
     if (!x || !out || rows <= 0 || C <= 0) return VDA_EINVAL;
     if (act < VDA_SPLIT_NONE || act > VDA_SPLIT_GEGLU) return VDA_EINVAL;
     if ((out_type != VDA_T_BF16 && out_type != VDA_T_F16) || !(scale > 0.f)) return VDA_EINVAL;
@@ -269,10 +268,10 @@ extern "C" int vda_split3(const float* x, void* out, long rows, int C, int ldx, 
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (out_type == VDA_T_F16)
         hipLaunchKernelGGL(split3_kernel<f16>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                           reinterpret_cast<f16*>(out), rows, C, ldx, Cp, act, scale);
+                           reinterpret_cast<f16*>(out), rows, C, ldx, Cp, act, scale, sat_flag);
     else
         hipLaunchKernelGGL(split3_kernel<bf16>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                           reinterpret_cast<bf16*>(out), rows, C, ldx, Cp, act, scale);
+                           reinterpret_cast<bf16*>(out), rows, C, ldx, Cp, act, scale, sat_flag);
     return hip_rc(hipGetLastError());
 }
 

@@ -12,11 +12,12 @@ packed [hi | hi | lo]), so the same MFMA kernels accumulate the three-term hi/lo
 torch is used for allocation (caching allocator = workspace reuse) and the stream only.
 """
 import os
+import warnings
 
 import torch
 
 from . import hip
-from .packing import ACT_SPLIT_SCALE, SPLIT_DTYPE, SplitWeight
+from .packing import ACT_SPLIT_SCALE, MIN_ACT_SPLIT_SCALE, SPLIT_DTYPE, SplitWeight
 from .spec import TEMPORAL_HEADS
 
 BF16 = torch.bfloat16
@@ -26,14 +27,37 @@ def _empty(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
+class Triple:
+    """Marks a 16-bit matrix [rows, 3K] that already holds the [hi | lo | hi] pieces of an fp32 operand (written by the kernel
+    that produced the values), so that ``Engine.operand`` does not split it again."""
+
+    def __init__(self, t):
+        self.t = t
+
+
+class SaturationError(FloatingPointError):
+    pass
+
+
 class Engine:
     def __init__(self, packed):
         self.w = packed
         self.dev = packed.device
-        self.split = packed.precision == "fp32"
+        # fp32 storage + three-term products, per part of the network (packing.PRECISIONS); ``split`` is the setting of the
+        # part whose launches are being enqueued
+        self.split_enc, self.split_head, self.split_tail = packed.split_enc, packed.split_head, packed.split_tail
+        self.split = self.split_enc
         self.hdt = packed.head_dtype         # storage/operand type of the DPT head and the temporal modules
-        self.edt = torch.float32 if self.split else BF16      # storage type of the encoder's GEMM operands
+        self.edt = torch.float32 if self.split_enc else BF16      # storage type of the encoder's GEMM operands
+        # fp32 storage: the power of two every activation is multiplied by before it is split into IEEE halves.  16 keeps a
+        # normal low half for values down to 2^-7 and holds |values| below 4094; a window in which some scaled value leaves
+        # the half range (``sat`` is set by the kernel that saw it) is run again with the scale divided by 16, and the lower
+        # scale is kept from then on (see forward)
         self.act_scale = ACT_SPLIT_SCALE if SPLIT_DTYPE == torch.float16 else 1.0
+        self.sat = torch.zeros(1, dtype=torch.int32, device=self.dev) if self.dev.type == "cuda" else None
+        # fp32 storage: the producers write the 16-bit pieces of their fp32 results themselves (LayerNorm, the QKV and fc1
+        # products, attention) instead of an fp32 matrix that a vda_split3 pass then reads; False keeps the separate passes
+        self.fused_split = SPLIT_DTYPE == torch.float16
         self.encoder_streams = 2      # frame groups of the encoder that run on concurrent streams (see encoder())
         self.side_streams = []
         self.head_streams = 2         # 2: parts of the head run on the first side stream beside the rest (see head())
@@ -51,6 +75,9 @@ class Engine:
     def operand(self, a, relu=False, act=None):
         """The MFMA operand of activation matrix ``a`` [rows, K]: itself, or its bf16 [hi | lo | hi] split in fp32 mode
         (``act``: an activation the split applies first; GEGLU halves the width)."""
+        if isinstance(a, Triple):
+            assert act is None and not relu
+            return a.t, False
         if not self.split:
             assert act is None
             return a, relu
@@ -58,7 +85,7 @@ class Engine:
         if act == hip.SPLIT_GEGLU:
             K //= 2
         a3 = _empty((rows, 3 * K), SPLIT_DTYPE, self.dev)
-        hip.split3(a, a3, rows, K, a.stride(0), K, relu=relu, act=act, scale=self.act_scale)
+        hip.split3(a, a3, rows, K, a.stride(0), K, relu=relu, act=act, scale=self.act_scale, sat_flag=self.sat)
         return a3, False
 
     def weight(self, w, kw):
@@ -122,14 +149,17 @@ class Engine:
         the other frames of its window, and consecutive windows of a video share ten of 32 frames, video_depth.py:157-164)."""
         w, dev = self.w, self.dev
         hw = (H // 14) * (W // 14)
-        taps = [_empty((frames * hw, w.D), self.hdt, dev) for _ in w.taps]
+        # (fp32 head: the tap norms write the operand pieces of the head's first products directly, see Triple)
+        self.taps_split = self.split_head and self.fused_split
+        taps = [_empty((frames * hw, 3 * w.D), SPLIT_DTYPE, dev) if self.taps_split else _empty((frames * hw, w.D), self.hdt, dev)
+                for _ in w.taps]
         first = 0
         if carried is not None:
             prev, slots = carried
             first = len(slots)
             idx = torch.tensor(slots, dtype=torch.int64, device=dev)
             for t, p in zip(taps, prev):
-                torch.index_select(p.view(-1, hw * w.D), 0, idx, out=t[:first * hw].view(first, hw * w.D))
+                torch.index_select(p.view(-1, hw * p.shape[1]), 0, idx, out=t[:first * hw].view(first, hw * t.shape[1]))
         if first == frames:
             return taps
         w.pos_table(H // 14, W // 14)             # built (and uploaded) on this stream before any other stream reads it
@@ -160,12 +190,13 @@ class Engine:
     def folds_layernorms(self):
         """Whether the encoder blocks' LayerNorms are folded into qkv / fc1 on this engine."""
         D = self.w.D
-        return (D < 1024 if self.fold_layernorm is None else bool(self.fold_layernorm)) and not self.split and D % 64 == 0
+        return (D < 1024 if self.fold_layernorm is None else bool(self.fold_layernorm)) and not self.split_enc and D % 64 == 0
 
     def encoder_frames(self, x, f0, f1, H, W, taps):
         """Frames f0..f1-1 through the encoder on the current stream; writes their rows of the tap buffers."""
         w, dev = self.w, self.dev
         D, heads = w.D, w.heads
+        self.split = self.split_enc
         frames = f1 - f0
         x = x[f0:f1]
         hp, wp = H // 14, W // 14
@@ -178,10 +209,19 @@ class Engine:
         xs = _empty((M, D), torch.float32, dev)
         hip.assemble_tokens(tok, w.cls, w.pos_table(hp, wp), xs, frames, hw, D)
         del cols, tok
-        y = _empty((M, D), self.edt, dev)
-        qkv = _empty((M, 3 * D), self.edt, dev)
-        att = _empty((M, D), self.edt, dev)
-        hid = _empty((M, 4 * D), self.edt, dev)
+        pieces = self.split and self.fused_split       # fp32 storage with the operand pieces written by the producers
+        tap_kw = dict(split_scale=self.act_scale, sat_flag=self.sat) if self.taps_split else {}
+        if pieces:
+            S = dict(split_scale=self.act_scale, sat_flag=self.sat)
+            y = _empty((M, 3 * D), SPLIT_DTYPE, dev)         # [hi | lo | hi] of the normed rows
+            qkv = _empty((M, 6 * D), SPLIT_DTYPE, dev)       # [hi | lo] of q, k, v
+            att = _empty((M, 3 * D), SPLIT_DTYPE, dev)
+            hid = _empty((M, 12 * D), SPLIT_DTYPE, dev)      # [hi | lo | hi] of GELU(fc1)
+        else:
+            y = _empty((M, D), self.edt, dev)
+            qkv = _empty((M, 3 * D), self.edt, dev)
+            att = _empty((M, D), self.edt, dev)
+            hid = _empty((M, 4 * D), self.edt, dev)
         tap = 0
         # Folded LayerNorm (block.py:84,87): no normalisation pass over the residual stream.  The product that updates the
         # stream (proj, fc2) also writes the updated rows rounded to 16 bits into y, with partial sums per 64 columns;
@@ -207,6 +247,14 @@ class Engine:
                 else:
                     self.linear(hid, b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D, out16=y, row_part=part)
                     hip.rowstats_finish(part, stat, M, slots, 1e-6)
+            elif pieces:
+                hip.layernorm(xs, y, b["ln1_w"], b["ln1_b"], M, D, 1e-6, **S)
+                self.linear(Triple(y), b["wqkv"], qkv, b["bqkv"], split_out=2, **S)
+                hip.attention_pairs(qkv, att, frames, N, heads, self.act_scale)
+                self.linear(Triple(att), b["wproj"], xs, b["bproj"], resid=xs, ldr=D)
+                hip.layernorm(xs, y, b["ln2_w"], b["ln2_b"], M, D, 1e-6, **S)
+                self.linear(Triple(y), b["wfc1"], hid, b["bfc1"], act=hip.ACT_GELU, split_out=3, **S)      # the exact GELU
+                self.linear(Triple(hid), b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D)
             else:
                 hip.layernorm(xs, y, b["ln1_w"], b["ln1_b"], M, D, 1e-6)
                 self.linear(y, b["wqkv"], qkv, b["bqkv"])
@@ -222,7 +270,7 @@ class Engine:
             if i in w.taps:
                 t = taps[tap][f0 * hw:f1 * hw]
                 tap += 1
-                hip.layernorm(xs, t, w.norm_w, w.norm_b, frames * hw, D, 1e-6, rows_per_group=hw, in_group=N, in_skip=1)
+                hip.layernorm(xs, t, w.norm_w, w.norm_b, frames * hw, D, 1e-6, rows_per_group=hw, in_group=N, in_skip=1, **tap_kw)
 
     # ---- temporal module (reference: motion_module.py:102-126, 164-177, 230-297) ----------------------------------------
     def motion(self, idx, x, B, T):
@@ -236,16 +284,22 @@ class Engine:
         hip.groupnorm(xf, g, m["gn_w"], m["gn_b"], work, f, hw, C, 32, 1e-6)
         hs = _empty((M, C), torch.float32, dev)
         self.linear(g, m["in_w"], hs, m["in_b"])
-        n = g                                            # reuse as the normed-activation buffer
+        pieces = self.split and self.fused_split
+        if pieces:      # fp32 storage: the norms write the operand pieces of the products that follow them
+            n, ln_kw = Triple(_empty((M, 3 * C), SPLIT_DTYPE, dev)), dict(split_scale=self.act_scale, sat_flag=self.sat)
+            n_out = n.t
+        else:
+            n, ln_kw = g, {}                             # reuse as the normed-activation buffer
+            n_out = n
         qkv = _empty((M, 3 * C), self.hdt, dev)
         o = _empty((M, C), self.hdt, dev)
         hd = C // TEMPORAL_HEADS
         for a in m["attn"]:
-            hip.layernorm(hs, n, a["ln_w"], a["ln_b"], M, C, 1e-5, pe=a["pe"], pe_hw=hw, pe_T=T)
+            hip.layernorm(hs, n_out, a["ln_w"], a["ln_b"], M, C, 1e-5, pe=a["pe"], pe_hw=hw, pe_T=T, **ln_kw)
             self.linear(n, a["wqkv"], qkv)
             hip.temporal_attention(qkv, o, B, T, hw, TEMPORAL_HEADS, hd, hd ** -0.5)
             self.linear(o, a["wo"], hs, a["bo"], resid=hs, ldr=C)
-        hip.layernorm(hs, n, m["ffn_w"], m["ffn_b"], M, C, 1e-5)
+        hip.layernorm(hs, n_out, m["ffn_w"], m["ffn_b"], M, C, 1e-5, **ln_kw)
         if self.split:          # fp32 storage: plain projection to [values | gates], the gated GELU runs in ff2's operand split
             ff = _empty((M, 8 * C), self.hdt, dev)
             self.linear(n, m["ff1_w"], ff, m["ff1_b"])
@@ -277,12 +331,13 @@ class Engine:
     # ---- DPT head (reference: dpt_temporal.py:53-114, dpt.py:60-124) ---------------------------------------------------
     def head(self, taps, B, T, hp, wp):
         w, dev = self.w, self.dev
+        self.split = self.split_head
         frames = B * T
         hw = hp * wp
         proj = []
         for i in range(4):
             p = _empty((frames * hw, w.ocp[i]), self.hdt, dev)
-            self.linear(taps[i], w.proj_w[i], p, w.proj_b[i])
+            self.linear(Triple(taps[i]) if self.taps_split else taps[i], w.proj_w[i], p, w.proj_b[i])
             proj.append(p)
         # The four pyramid branches are independent until the fusion blocks join them, the coarsest first.  The coarsest
         # branch (stride-2 conv, temporal module, fusion block, temporal module: 19 x 19 and 37 x 37 maps, grids that fill a
@@ -327,12 +382,21 @@ class Engine:
         # From here on every stage works frame by frame (two fusion blocks, the output convolutions): two halves of the
         # frames on the two streams, as in the encoder.
         depth = _empty((frames, 14 * hp, 14 * wp), torch.float32, dev)
-        narrow = not self.split and w.F2 < w.F2p and w.F2 % 32 == 0
+        narrow = not self.split_tail and w.F2 < w.F2p and w.F2 % 32 == 0
 
         def tail(f0, f1):
             p2 = self.fusion(2, p3[f0:f1], r2[f0:f1], 4 * hp, 4 * wp)
             # the two largest resamplings (to 8x and 14x the patch grid) are folded into the convolutions that read them
             p1 = self.fusion(1, p2, r1[f0:f1], 8 * hp, 8 * wp, resize=False)
+            if self.split_tail and not self.split_head:      # measurement form: only the output stage in fp32 storage
+                self.split, self.hdt, p1, hdt16 = True, torch.float32, p1.float(), self.hdt
+                try:
+                    o1 = self.conv3(p1, w.oc1_w, w.oc1_b, w.F2p, resized=(8 * hp, 8 * wp))
+                    self.conv3(o1, w.oc2_w, w.oc2_b, 32, out=depth[f0:f1], ldc=4, epi=hip.EPI_DOT, dot_w=w.dot_w, dot_b=w.dot_b,
+                               resized=(14 * hp, 14 * wp))
+                finally:
+                    self.split, self.hdt = False, hdt16
+                return
             if narrow:      # ViT-S: 32 channels in a map stored 64 wide; the padding is neither computed nor read
                 o1 = _empty((f1 - f0, 8 * hp, 8 * wp, w.F2p), self.hdt, dev)
                 self.conv3(p1, w.oc1_w[:w.F2], w.oc1_b[:w.F2], w.F2, out=o1, ldc=w.F2p, resized=(8 * hp, 8 * wp))
@@ -378,7 +442,24 @@ class Engine:
                     n += 1
                 if n:
                     carried = (kept["taps"], [kept["slot"][k] for k in frame_keys[:n]])
-        taps = self.encoder(x.reshape(B * T, ch, H, W), B * T, H, W, carried)
+        while True:
+            taps = self.encoder(x.reshape(B * T, ch, H, W), B * T, H, W, carried)
+            depth = self.head(taps, B, T, hp, wp).reshape(B, T, H, W)
+            if not (self.split_enc or self.split_head or self.split_tail) or SPLIT_DTYPE != torch.float16:
+                break
+            # fp32 storage: did some activation, times act_scale, leave the IEEE-half range (its high piece then saturated)?
+            # One 4-byte read per window, which waits for the window; this mode's windows take a hundred milliseconds.
+            if not int(self.sat.item()):
+                break
+            self.sat.zero_()
+            if self.act_scale <= MIN_ACT_SPLIT_SCALE:
+                raise SaturationError(f"fp32 storage mode: an activation exceeds {65504 / self.act_scale:.3g} in magnitude, beyond the "
+                                      "range of the hi/lo half pieces at the smallest operand scale")
+            self.act_scale /= 16.0
+            warnings.warn(f"fp32 storage mode: an activation left the IEEE-half range of the operand pieces; the operand scale "
+                          f"is lowered to {self.act_scale:g} (|values| up to {65504 / self.act_scale:.3g}) and the window is "
+                          f"computed again", RuntimeWarning, stacklevel=3)
+            carried, self.kept = None, None        # kept operand pieces carry the old scale
         if keyed:
             self.kept = dict(size=(H, W), slot={k: i for i, k in enumerate(frame_keys)}, taps=taps)
-        return self.head(taps, B, T, hp, wp).reshape(B, T, H, W)
+        return depth

@@ -72,6 +72,9 @@ ACT_SPLIT_SCALE = 16.0           # power of two every fp32 activation is multipl
 #                                  values down to 2^-7 keep a normal low half, values up to 4094 fit the high half
 
 
+MIN_ACT_SPLIT_SCALE = 2.0 ** -8  # the engine lowers the scale by factors of 16 when a value saturates, down to this (values to 1.6e7)
+
+
 class SplitWeight:
     """A weight matrix packed for the fp32 mode: ``t`` = 16-bit [..., 3K] laid out [hi | hi | lo] along the last axis (the
     activation side is [hi | lo | hi], see vda_split3), pieces of ``scale * w``; ``scale`` is the power of two that puts
@@ -101,14 +104,24 @@ def split_weight(w):
     return SplitWeight(w)
 
 
+# precision -> which parts keep fp32 activations and multiply three-term hi/lo products: (encoder, head, output stage).
+# "half" and "fp32" are the two modes of the model; the mixed ones exist to measure what each part contributes to the error
+# (tools/clamped_parity.py): "enc32" = fp32 encoder + 16-bit head, "head32" = bf16 encoder + fp32 head, "tail32" = 16-bit
+# everywhere except output_conv1 / output_conv2 (the reference's own fp32 island, dpt_temporal.py:97-100, and the
+# convolution in front of it).
+PRECISIONS = {"half": (False, False, False), "fp32": (True, True, True), "enc32": (True, False, False),
+              "head32": (False, True, True), "tail32": (False, False, True)}
+
+
 class PackedWeights:
     """Device-resident kernel-layout weights of one model.  ``precision`` "fp32" packs every matrix as 16-bit hi/lo triples
-    (``SplitWeight``) for the fp32 storage mode (``head_dtype`` is then ignored)."""
+    (``SplitWeight``) for the fp32 storage mode (``head_dtype`` is then ignored); see PRECISIONS for the mixed forms."""
 
     def __init__(self, sd, encoder, features, out_channels, device, head_dtype=torch.float16, precision="half"):
         self.device = device
         self.precision = precision
-        self.head_dtype = torch.float32 if precision == "fp32" else head_dtype
+        self.split_enc, self.split_head, self.split_tail = PRECISIONS[precision]
+        self.head_dtype = torch.float32 if self.split_head else head_dtype
         self.encoder = encoder
         D, depth, heads, taps = ENCODERS[encoder]
         self.D, self.depth, self.heads, self.taps = D, depth, heads, taps
@@ -120,11 +133,9 @@ class PackedWeights:
         self._pos_cache = {}
         g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32)  # noqa: E731
         f32 = lambda t: t.contiguous()  # noqa: E731
-        if precision == "fp32":
-            bf = hd_ = split_weight
-        else:
-            bf = lambda t: t.to(BF16).contiguous()  # noqa: E731
-            hd_ = lambda t: t.to(head_dtype).contiguous()  # noqa: E731
+        bf = split_weight if self.split_enc else (lambda t: t.to(BF16).contiguous())
+        hd_ = split_weight if self.split_head else (lambda t: t.to(head_dtype).contiguous())
+        hd_all = hd_
 
         def padded(t, rows, cols):
             out = torch.zeros((rows, cols), dtype=torch.float32, device=device)
@@ -167,7 +178,7 @@ class PackedWeights:
             ln1_w, ln1_b, ln2_w, ln2_b = g(b + "norm1.weight"), g(b + "norm1.bias"), g(b + "norm2.weight"), g(b + "norm2.bias")
             wfc1, bfc1 = g(b + "mlp.fc1.weight"), g(b + "mlp.fc1.bias")
             folded = {}
-            if precision != "fp32":
+            if not self.split_enc:
                 # LayerNorm folded into the product that follows it (block.py:84,87): with W' = W diag(ln_w) rounded to the
                 # operand type,  LN(x) W^T + b = rstd (x W'^T - mean colsum(W')) + (b + W ln_b).  The product reads the rows
                 # of x rounded to 16 bits (written, with their sums, by the product before it) and normalises its sums.
@@ -206,10 +217,12 @@ class PackedWeights:
                     d[f"u{u}c{c}_w"] = conv3(f"{r}resConfUnit{u}.conv{c}.weight", Fp, Fp)
                     d[f"u{u}c{c}_b"] = padvec(g(f"{r}resConfUnit{u}.conv{c}.bias"), Fp)
             self.refine[i] = d
+        hd_ = split_weight if self.split_tail else hd_all
         self.oc1_w, self.oc1_b = conv3(sc + "output_conv1.weight", F2p, Fp), padvec(g(sc + "output_conv1.bias"), F2p)
         self.oc2_w, self.oc2_b = conv3(sc + "output_conv2.0.weight", 32, F2p), f32(g(sc + "output_conv2.0.bias"))
         self.dot_w = f32(g(sc + "output_conv2.2.weight").reshape(32))
         self.dot_b = float(sd[sc + "output_conv2.2.bias"].detach().float().reshape(-1)[0].item())
+        hd_ = hd_all
 
         self.motion = []
         for i, C in enumerate((self.oc[2], self.oc[3], self.F, self.F)):

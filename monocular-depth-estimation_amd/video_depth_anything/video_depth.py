@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import hip
 from .engine import Engine
-from .packing import PackedWeights
+from .packing import PRECISIONS, PackedWeights
 from .spec import ENCODERS, state_dict_spec
 from .windows import INFER_LEN, KEYFRAMES, OVERLAP
 
@@ -117,8 +117,8 @@ class VideoDepthAnything(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("VideoDepthAnything (MI355X build) has no CPU path: call .to('cuda') on a ROCm device first")
         hip.lib()
-        if self.precision not in ("half", "fp32"):
-            raise ValueError(f"precision {self.precision!r}: expected 'half' or 'fp32'")
+        if self.precision not in PRECISIONS:
+            raise ValueError(f"precision {self.precision!r}: expected 'half' or 'fp32' (or a measurement form of packing.PRECISIONS)")
         key = self._weights_key()
         cached = self._engines.get(self.precision)
         if cached is None or cached[0] != key:

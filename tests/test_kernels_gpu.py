@@ -739,6 +739,127 @@ def test_attention_fp32_mode(frames, n_tok, heads):
     close(out, want, 3e-6, "attention, fp32 mode")
 
 
+# ---- fp32 mode: the producers write the operand pieces themselves ------------------------------------------------------------
+def pieces_of(ref, piece=torch.float16):
+    hi = ref.clamp(-65504.0, 65504.0).to(piece) if piece == torch.float16 else ref.to(piece)
+    lo = (ref - hi.float()).to(piece)
+    return hi, lo
+
+
+@pytest.mark.parametrize("piece", HALVES)
+@pytest.mark.parametrize("rows,C", [(2740, 1024), (100, 384), (37, 64)])
+def test_layernorm_writes_operand_pieces(rows, C, piece):
+    """vda_layernorm with split_scale: the rows vda_split3 would make of the fp32 result, bit for bit."""
+    x = rnd((rows, C), 1, 2.0, torch.float32) + 0.3
+    w, b = rnd((C,), 2, 0.3, torch.float32) + 1.0, rnd((C,), 3, 0.2, torch.float32)
+    y = torch.empty((rows, C), dtype=torch.float32, device=DEV)
+    hip.layernorm(x, y, w, b, rows, C, 1e-6)
+    want = torch.empty((rows, 3 * C), dtype=piece, device=DEV)
+    hip.split3(y, want, rows, C, C, C, scale=ACT_SCALE[piece])
+    got = torch.full((rows, 3 * C), float("nan"), dtype=piece, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.layernorm(x, got, w, b, rows, C, 1e-6, split_scale=ACT_SCALE[piece], sat_flag=flag)
+    assert torch.equal(got, want) and int(flag.item()) == 0
+    hip.layernorm(x, got, w * 4000.0, b, rows, C, 1e-6, split_scale=ACT_SCALE[piece], sat_flag=flag)      # |y| up to ~1.6e4
+    assert int(flag.item()) == (1 if piece == torch.float16 else 0) and bool(torch.isfinite(got.float()).all())
+
+
+@pytest.mark.parametrize("cfg", [1, 2])
+@pytest.mark.parametrize("piece", HALVES)
+@pytest.mark.parametrize("M,N,K,segs,gelu", [(1370, 3072, 1024, 2, False), (333, 1536, 384, 3, True), (300, 4096, 1024, 3, True),
+                                              (40, 192, 64, 3, False), (700, 64, 128, 2, False)])
+def test_gemm_writes_its_output_as_operand_pieces(M, N, K, segs, gelu, piece, cfg):
+    """VdaGemmArgs.split_out: the three-term product's result (with the exact GELU where asked) stored as the [hi | lo] or
+    [hi | lo | hi] pieces of split_scale * v instead of an fp32 matrix: what vda_split3 makes of the fp32 output of the same
+    product, up to the summation-order-free arithmetic both share (bit for bit without GELU; with it, both evaluate the same
+    erf form on the same sums)."""
+    if cfg == 2 and N < 192:
+        pytest.skip("the 256x256 tile is not offered for narrow outputs")
+    sc = ACT_SCALE[piece]
+    a, w = rnd((M, K), 1, 1.0, torch.float32), rnd((N, K), 2, 1 / math.sqrt(K), torch.float32)
+    bias = rnd((N,), 3, 0.1, torch.float32)
+    a3 = torch.empty((M, 3 * K), dtype=piece, device=DEV)
+    hip.split3(a, a3, M, K, K, K, scale=sc)
+    sw = split_w(w, piece)
+    kw = dict(M=M, N=N, K=3 * K, lda=3 * K, bias=bias, tile_cfg=cfg, acc_scale=1.0 / (sw.scale * sc))
+    plain = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    hip.gemm(a3, sw.t, plain, ldc=N, **kw)
+    want = torch.empty((M, 3 * N), dtype=piece, device=DEV)
+    hip.split3(plain, want, M, N, N, N, act=hip.SPLIT_GELU if gelu else hip.SPLIT_NONE, scale=sc)
+    ld = segs * N + 64                                      # a row stride beyond the segments
+    got = torch.full((M, ld), float("nan"), dtype=piece, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.gemm(a3, sw.t, got, ldc=ld, act=hip.ACT_GELU if gelu else hip.ACT_NONE, split_out=segs, split_scale=sc, sat_flag=flag, **kw)
+    if gelu:        # the same erf form on the same sums, but compiled into two kernels: equal up to a fused multiply-add or two
+        sum_got, sum_want = got[:, :N].float() + got[:, N:2 * N].float(), want[:, :N].float() + want[:, N:2 * N].float()
+        assert (sum_got - sum_want).abs().max() <= SPLIT_TOL[piece] * sum_want.abs().max()
+        if segs == 3:
+            assert torch.equal(got[:, :N], got[:, 2 * N:3 * N])
+    else:
+        assert torch.equal(got[:, :segs * N], want[:, :segs * N])
+    assert bool(torch.isnan(got[:, segs * N:].float()).all()) and int(flag.item()) == 0
+    exact = a.double() @ w.double().t() + bias.double()
+    exact = F.gelu(exact) if gelu else exact
+    close((got[:, :N].float() + got[:, N:2 * N].float()) / sc, exact.float(), SPLIT_TOL[piece], "pieces of the product")
+    if piece == torch.float16:      # a scaled value beyond the half range sets the flag, and only then
+        hip.gemm(a3, sw.t, got, ldc=ld, split_out=segs, split_scale=sc * 2.0 ** 16, sat_flag=flag, **kw)
+        assert int(flag.item()) == 1 and bool(torch.isfinite(got[:, :segs * N].float()).all())
+    with pytest.raises(RuntimeError):            # no residual form
+        hip.gemm(a3, sw.t, got, ldc=ld, split_out=segs, split_scale=sc, resid=plain, ldr=N, **kw)
+
+
+@pytest.mark.parametrize("frames,n_tok,heads", [(2, 1370, 2), (1, 129, 3), (2, 36, 1), (1, 700, 16)])
+def test_attention_on_operand_pieces(frames, n_tok, heads):
+    """vda_attention_pairs: [hi | lo] pieces of 16 * qkv in, [hi | lo | hi] pieces of 16 * output out, against fp64."""
+    D, sc = heads * 64, 16.0
+    qkv = rnd((frames, n_tok, 3 * D), 1, 1.0, torch.float32)
+    qkv[..., :D] *= 0.35
+    hi, lo = pieces_of(qkv * sc)
+    qkv2 = torch.cat([hi, lo], dim=-1).contiguous()
+    out3 = torch.full((frames, n_tok, 3 * D), float("nan"), dtype=torch.float16, device=DEV)
+    hip.attention_pairs(qkv2, out3, frames, n_tok, heads, sc)
+    q, k, v = qkv.double().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    want = (softmax2(q @ k.transpose(-1, -2)) @ v).transpose(1, 2).reshape(frames, n_tok, D).float()
+    got = (out3[..., :D].float() + out3[..., D:2 * D].float()) / sc
+    close(got, want, 3e-6, "attention on pieces")
+    assert torch.equal(out3[..., :D], out3[..., 2 * D:])
+    old = torch.empty((frames, n_tok, D), dtype=torch.float32, device=DEV)
+    hip.attention(qkv, old, frames, n_tok, heads)
+    close(got, old, 2e-6, "against the fp32-in / fp32-out form")
+
+
+def test_attention_on_operand_pieces_with_scores_far_from_zero():
+    """Sharp and shifted softmax rows: the running maximum moves (the deferred rescale branch), in units of scale^2."""
+    frames, n_tok, heads, sc = 1, 300, 2, 16.0
+    D = heads * 64
+    qkv = rnd((frames, n_tok, 3 * D), 5, 1.0, torch.float32)
+    qkv[..., :D] *= 3.0
+    qkv[:, :, D:2 * D] += 2.0 * torch.arange(n_tok, device=DEV, dtype=torch.float32)[None, :, None] / n_tok      # later keys score higher
+    hi, lo = pieces_of(qkv * sc)
+    out3 = torch.empty((frames, n_tok, 3 * D), dtype=torch.float16, device=DEV)
+    hip.attention_pairs(torch.cat([hi, lo], dim=-1).contiguous(), out3, frames, n_tok, heads, sc)
+    q, k, v = qkv.double().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    want = (softmax2(q @ k.transpose(-1, -2)) @ v).transpose(1, 2).reshape(frames, n_tok, D).float()
+    close((out3[..., :D].float() + out3[..., D:2 * D].float()) / sc, want, 1e-5, "attention on pieces, sharp rows")
+
+
+def test_split3_reports_saturation():
+    x = rnd((64, 128), 1, 1.0, torch.float32)
+    out = torch.empty((64, 3 * 128), dtype=torch.float16, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.split3(x, out, 64, 128, 128, 128, scale=16.0, sat_flag=flag)
+    assert int(flag.item()) == 0
+    x[17, 5] = -5000.0                                        # 16 * 5000 > 65504
+    hip.split3(x, out, 64, 128, 128, 128, scale=16.0, sat_flag=flag)
+    assert int(flag.item()) == 1 and float(out[17, 5]) == -65504.0
+    flag.zero_()
+    hip.split3(x, out, 64, 128, 128, 128, scale=1.0, sat_flag=flag)
+    assert int(flag.item()) == 0
+    bf = torch.empty((64, 3 * 128), dtype=BF, device=DEV)
+    hip.split3(x * 1e6, bf, 64, 128, 128, 128, scale=1.0, sat_flag=flag)             # bf16 pieces have fp32's range
+    assert int(flag.item()) == 0
+
+
 @pytest.mark.parametrize("cfg", [1, 2])
 def test_gemm_fp16_outputs_saturate_instead_of_overflowing(cfg):
     """A sum beyond the IEEE-half range (a real checkpoint's activation outlier) is stored as +-65504, not as infinity: the

@@ -1,0 +1,65 @@
+"""Error and speed of every precision form (packing.PRECISIONS: the two modes of the model and the mixed measurement
+forms) on depth maps with clamped pixels: the ViT-S goldens of the reference (G4b forward, G5b video), ViT-L 1x8x3x518x518
+against the oracle executed on the device, and the ViT-L 32-frame window rate.    python tools/precision_table.py [--no-vitl]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "monocular-depth-estimation_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import vda_oracle as O
+from video_depth_anything import spec
+from video_depth_anything.packing import PRECISIONS
+from video_depth_anything.video_depth import VideoDepthAnything
+
+MODES = [m for m in ("half", "tail32", "head32", "enc32", "fp32") if m in PRECISIONS]
+
+
+def line(name, got, want):
+    err = np.abs(got.astype(np.float64) - want)
+    print(f"{name:40s} max_rel(floor 1e-3)={O.max_rel_err(got, want):.3e} abs_rel={O.abs_rel(got, want):.3e} "
+          f"max|err|/max={err.max() / want.max():.3e} zeros={np.mean(want == 0):.3f} "
+          f"flipped={np.mean((want == 0) != (got == 0)):.5f}", flush=True)
+
+
+def build(enc, profile):
+    cfg = spec.MODEL_CONFIGS[enc]
+    sd = {k: torch.from_numpy(v) for k, v in spec.synth_state_dict(**cfg, seed=1, profile=profile).items()}
+    m = VideoDepthAnything(**cfg)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval(), sd
+
+
+m, _ = build("vits", "clamped")
+g4 = np.load(os.path.join(ROOT, "tests/golden/g4b_forward_clamped.npz"))
+g5 = np.load(os.path.join(ROOT, "tests/golden/g5b_video_clamped.npz"))
+for mode in MODES:
+    m.precision = mode
+    for name, shape, seed in (("T32", (1, 32, 3, 70, 98), 41), ("B2T3", (2, 3, 3, 56, 42), 43)):
+        x = torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32)).cuda()
+        line(f"vits {mode} forward {name}", m(x).cpu().numpy(), g4[name])
+    frames = np.random.RandomState(760).randint(0, 256, (60, 28, 42, 3)).astype(np.uint8)
+    out, _ = m.infer_video_depth(frames, 24, input_size=28, device="cuda", batch_size=32)
+    line(f"vits {mode} video N60 bs32", out, g5["N60_bs32"])
+del m
+if "--no-vitl" not in sys.argv:
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    m, sd = build("vitl", "clamped")
+    sd_dev = {k: v.cuda() for k, v in sd.items()}
+    x8 = torch.from_numpy(np.random.RandomState(2).standard_normal((1, 8, 3, 518, 518)).astype(np.float32)).cuda()
+    want = O.forward(sd_dev, x8, "vitl").cpu().numpy()
+    x32 = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 32, 3, 518, 518)).astype(np.float32)).cuda()
+    for mode in MODES:
+        m.precision = mode
+        line(f"vitl {mode} 1x8x3x518x518", m(x8).cpu().numpy(), want)
+        for _ in range(2):
+            m(x32)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps = 5
+        for _ in range(steps):
+            m(x32)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        print(f"vitl {mode:8s} 32-frame window {1e3 * dt:.1f} ms = {32 / dt:.1f} frames/s", flush=True)
+        m._engines.pop(mode, None)
+        torch.cuda.empty_cache()
