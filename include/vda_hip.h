@@ -13,11 +13,17 @@
  *
  * Two storage modes share these entry points.  The default keeps activations in 16 bits.  The fp32 mode (the
  * reference's fp32=True, video_depth.py:67,136) keeps every activation in fp32 (dtype / out_type VDA_T_F32 below) and
- * still multiplies on the 16-bit matrix cores: vda_split3 turns an fp32 operand into 16-bit triples [hi | lo | hi], weights
- * are packed [hi | hi | lo], and one vda_gemm pass over K' = 3K accumulates hi*hi + lo*hi + hi*lo in fp32, at a third of the
- * 16-bit rate instead of the sixteenth of the fp32 matrix cores.  With IEEE-half pieces (11 significant bits each, operands
- * pre-scaled by powers of two into the half range and the sums scaled back, VdaGemmArgs.acc_scale) a product is good to about
- * 2^-21 relative; with bf16 pieces (8 bits each, no scaling needed) to about 2^-16.
+ * still multiplies on the 16-bit matrix cores: an fp32 operand becomes 16-bit pieces hi = round(s v), lo = round(s v - hi)
+ * and a product is the three-term sum hi*hi + lo*hi + hi*lo accumulated in fp32, at a third of the 16-bit rate instead of the
+ * sixteenth of the fp32 matrix cores.  With IEEE-half pieces (11 significant bits each, operands pre-scaled by powers of two
+ * into the half range and the sums scaled back, VdaGemmArgs.acc_scale) a product is good to about 2^-21 relative; with bf16
+ * pieces (8 bits each, no scaling needed) to about 2^-16.  Two layouts of the pieces along K (VDA_PIECES_*):
+ *   TRIPLE  rows [hi | lo | hi] against weights [hi | hi | lo], each segment K wide: any vda_gemm pass over K' = 3K forms the
+ *           three terms without knowing about them;
+ *   PAIRS   every 32 columns of the operand are stored as 64: [hi 32 | lo 32], for activations and weights alike, and
+ *           VdaGemmArgs.ab_pairs tells the kernels, whose K step of 64 stored columns then holds both pieces of 32 operand
+ *           columns: they issue the three products from ONE copy of each piece (two thirds of the global -> LDS and LDS ->
+ *           register traffic of the triple form per product, and two thirds of the memory).
  */
 #ifndef VDA_HIP_H
 #define VDA_HIP_H
@@ -52,6 +58,7 @@ const char* vda_version(void);
  *   motion_module/attention.py:81-83,90 (via motion_module.py:242-250,290), attention.py:333,374,383-384.
  * ------------------------------------------------------------------------------------------------------------- */
 enum { VDA_A_LINEAR = 0, VDA_A_CONV3 = 1 };
+enum { VDA_PIECES_TRIPLE = 0, VDA_PIECES_PAIRS = 1 };   /* layouts of an fp32 operand's hi/lo pieces, see the file comment */
 enum { VDA_ACT_NONE = 0, VDA_ACT_GELU = 1, VDA_ACT_RELU = 2 };          /* GELU: the erf form, evaluated to 5.4e-5
                                                                            absolute (a fit of erf; 16-bit out_type only) */
 enum { VDA_T_NONE = 0, VDA_T_F32 = 1, VDA_T_BF16 = 2, VDA_T_F16 = 3 };   /* "half" below = BF16 or F16 (IEEE half)  */
@@ -119,15 +126,17 @@ typedef struct VdaGemmArgs {
     const float* w_colsum;  /* [N], required with row_stat                                                            */
     /* fp32 mode: the output written directly as the next product's 16-bit operand (what vda_split3 would make of the fp32
        result), so that neither the fp32 matrix nor a split pass over it exists. */
-    int   split_out;      /* 0 = off.  2 or 3: `out` is ab_type [M][ldc], ldc >= split_out * N, and receives the pieces of
-                             split_scale * v (v = the epilogue's result) in segments of N columns: [hi | lo] (2: the form
-                             vda_attention_pairs reads) or [hi | lo | hi] (3: the A operand of vda_gemm, see vda_split3).
+    int   split_out;      /* 0 = off.  2, 3 or 4: `out` is ab_type [M][ldc] and receives the pieces of split_scale * v (v = the
+                             epilogue's result): 2 = [hi | lo] in two segments of N columns (the form vda_attention_pairs
+                             reads), 3 = VDA_PIECES_TRIPLE, 4 = VDA_PIECES_PAIRS (2 N columns); ldc >= the row's width.
                              out_type is ignored.  With act VDA_ACT_GELU the exact erf form is evaluated (as VDA_SPLIT_GELU).
                              Needs A_LINEAR, EPI_PLAIN, no gamma, no residual, N % 64 == 0, 16-byte aligned out, ldc % 8 == 0;
                              else VDA_ESHAPE                                                                           */
     float split_scale;    /* power of two > 0 (see vda_split3's `scale`)                                                */
     int*  sat_flag;       /* NULL or one int in device memory that is set to 1 when a scaled value leaves the IEEE-half range
                              (|split_scale * v| > 65504; the piece saturates); never cleared here                        */
+    int   ab_pairs;       /* 1: a and w hold VDA_PIECES_PAIRS (K, lda, cin count STORED columns: twice the operand's); every
+                             K step multiplies hi*hi + hi*lo + lo*hi.  No relu_in, row_stat or out16.  0: plain operands    */
 } VdaGemmArgs;
 
 int vda_gemm(const VdaGemmArgs* args, void* stream);
@@ -152,11 +161,12 @@ int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, 
 
 /* The fp32 mode's attention on operands that are already split: qkv2 is IEEE half [frames][n_tok][2][3*heads*64], per token
  * the hi pieces of `scale` * [q | k | v] followed by the lo pieces (VdaGemmArgs.split_out = 2 of the fused QKV projection);
- * out3 is IEEE half [frames][n_tok][3][heads*64] = [hi | lo | hi] of `scale` * output: the A operand of the output projection.
+ * out3 holds the pieces of `scale` * output in `out_layout` (VDA_PIECES_TRIPLE: [frames][n_tok][3][heads*64];
+ * VDA_PIECES_PAIRS: [frames][n_tok][2*heads*64]): the A operand of the output projection.
  * Same arithmetic as vda_attention with dtype VDA_T_F32 (three-term products, fp32 softmax state), but K and V tiles go
  * global -> LDS without passing through registers and are not split again by every query block.  `scale` is the power of
  * two the producer used (q, k and v share it). */
-int vda_attention_pairs(const void* qkv2, void* out3, int frames, int n_tok, int heads, float scale, void* stream);
+int vda_attention_pairs(const void* qkv2, void* out3, int frames, int n_tok, int heads, float scale, int out_layout, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Row LayerNorm (biased variance, eps inside the sqrt): fp32 rows in, rows of out_type (BF16, F16 or F32) out.
@@ -164,13 +174,14 @@ int vda_attention_pairs(const void* qkv2, void* out3, int frames, int n_tok, int
  * token when taking the encoder taps (dinov2.py:310-312); with rows_per_group == in_group and in_skip == 0 it is the
  * identity map.  If pe != NULL, pe[((r / pe_hw) % pe_T)][c] (fp32 [pe_T][C]) is added after the affine step: the
  * temporal position table of motion_module.py:196-197 applied to rows ordered (frame, position).
- * split_scale != 0 (fp32 mode; out_type BF16 or F16, C % 64 == 0): the output rows are [rows][3*C], the [hi | lo | hi]
- * pieces of split_scale * y that vda_split3 would make of the fp32 result y; sat_flag as in VdaGemmArgs (may be NULL).
+ * split_scale != 0 (fp32 mode; out_type BF16 or F16, C % 64 == 0): the output rows are the pieces of split_scale * y in
+ * split_layout (VDA_PIECES_TRIPLE: [rows][3*C], VDA_PIECES_PAIRS: [rows][2*C]), what vda_split3 would make of the fp32 result
+ * y; sat_flag as in VdaGemmArgs (may be NULL).
  * Replaces block.py:84,87 (norm1/norm2), dinov2.py:310, motion_module.py:166,174.
  * ------------------------------------------------------------------------------------------------------------- */
 int vda_layernorm(const float* x, void* out, const float* weight, const float* bias, int rows, int C, float eps,
                   int rows_per_group, int in_group, int in_skip, const float* pe, int pe_hw, int pe_T, int out_type,
-                  float split_scale, int* sat_flag, void* stream);
+                  float split_scale, int split_layout, int* sat_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Row statistics for a LayerNorm that is folded into the product that follows it (VdaGemmArgs.row_stat; block.py:84,87).
@@ -228,8 +239,9 @@ int vda_im2col_patch14(const float* x, void* out, int frames, int H, int W, int 
 int vda_assemble_tokens(const float* tok, const float* cls, const float* pos, float* x, int frames, int hw, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * fp32 mode operand split: x fp32 [rows][ldx] -> out of out_type (BF16 or F16) [rows][3*Cp], segments [hi | lo | hi] of Cp
- * columns each (Cp % 64 == 0, columns C..Cp-1 zero, C % 4 == 0), hi = round(scale * v), lo = round(scale * v - hi); `scale` > 0
+ * fp32 mode operand split: x fp32 [rows][ldx] -> out of out_type (BF16 or F16): layout VDA_PIECES_TRIPLE [rows][3*Cp], segments
+ * [hi | lo | hi] of Cp columns each; VDA_PIECES_PAIRS [rows][2*Cp], every 32 columns as [hi 32 | lo 32]
+ * (Cp % 64 == 0, columns C..Cp-1 zero, C % 4 == 0), hi = round(scale * v), lo = round(scale * v - hi); `scale` > 0
  * is a power of two chosen by the caller (1 for bf16; for IEEE halves one that keeps |scale * v| below 65504 and the values
  * that matter above 2^-3, so that lo is a normal half; hi saturates instead of overflowing).  `act` is applied to v first,
  * because an activation cannot be applied to hi and lo separately:
@@ -244,8 +256,8 @@ int vda_assemble_tokens(const float* tok, const float* cls, const float* pos, fl
  * value (IEEE-half pieces only; the piece saturates).  No counterpart in the reference (its fp32 path multiplies in fp32).
  * ------------------------------------------------------------------------------------------------------------- */
 enum { VDA_SPLIT_NONE = 0, VDA_SPLIT_RELU = 1, VDA_SPLIT_GELU = 2, VDA_SPLIT_GEGLU = 3 };
-int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int act, int out_type, float scale, int* sat_flag,
-               void* stream);
+int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int act, int out_type, float scale, int layout,
+               int* sat_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Frame preprocessing: uint8 RGB frames [frames][h0][w0][3] -> fp32 [frames][3][H][W]: x/255, bicubic resize with

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restr
 // scaled), so the running maximum is kept in those units and a probability is exp2(s / scale^2 + log2 P_SCALE): one fused
 // multiply-add in front of the hardware exponential, whose result is already the scaled probability that is split.
 __global__ __launch_bounds__(256, 2) void attn_pairs_kernel(const f16* __restrict__ qkv, f16* __restrict__ out, int n_tok, int heads,
-                                                            int q_blocks, float s2) {
+                                                            int q_blocks, float s2, int out_form) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 32768];      // per buffer: K hi, K lo, V hi, V lo (8 KiB each)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void attn_pairs_kernel(const f16* __restric
     const float inv = 1.0f / l_tot;
     const int q = q0 + r;
     if (q < n_tok) {
-        f16* orow = out + ((size_t)frame * n_tok + q) * (3 * D) + head * 64 + 4 * h;
+        f16* orow = out + ((size_t)frame * n_tok + q) * pieces_width(out_form, D);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -552,23 +552,22 @@ __global__ __launch_bounds__(256, 2) void attn_pairs_kernel(const f16* __restric
                 const f32x4 v = {o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
                 f16x4 hi, lo;
                 split4<f16>(v, hi, lo);
-                f16* dst = orow + 32 * db + 8 * g;
-                *reinterpret_cast<f16x4*>(dst) = hi;
-                *reinterpret_cast<f16x4*>(dst + D) = lo;
-                *reinterpret_cast<f16x4*>(dst + 2 * D) = hi;
+                store_pieces<f16>(orow, head * 64 + 4 * h + 32 * db + 8 * g, D, out_form, hi, lo);
             }
     }
 }
 
 }  // namespace
 
-extern "C" int vda_attention_pairs(const void* qkv2, void* out3, int frames, int n_tok, int heads, float scale, void* stream) {
+extern "C" int vda_attention_pairs(const void* qkv2, void* out3, int frames, int n_tok, int heads, float scale, int out_layout,
+                                   void* stream) {
     if (!qkv2 || !out3 || frames <= 0 || n_tok <= 0 || heads <= 0 || !(scale > 0.f)) return VDA_EINVAL;
+    if (out_layout != VDA_PIECES_TRIPLE && out_layout != VDA_PIECES_PAIRS) return VDA_EINVAL;
     if ((((uintptr_t)qkv2 | (uintptr_t)out3) & 15) != 0) return VDA_ESHAPE;
     const int qb = (n_tok + 127) / 128;
     if ((long)frames * heads * qb > 0x7fffffffL) return VDA_ESHAPE;
     hipLaunchKernelGGL(attn_pairs_kernel, dim3(frames * heads * qb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const f16*>(qkv2), reinterpret_cast<f16*>(out3), n_tok, heads, qb, scale * scale);
+                       reinterpret_cast<const f16*>(qkv2), reinterpret_cast<f16*>(out3), n_tok, heads, qb, scale * scale, pieces_form(out_layout));
     return hip_rc(hipGetLastError());
 }
 

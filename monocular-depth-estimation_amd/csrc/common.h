@@ -115,4 +115,25 @@ __device__ __forceinline__ void split4(f32x4 v, typename Vec<T>::v4& hi, typenam
     }
 }
 
+// Where the pieces of an operand row go.  `form`: 2 = two planes [hi | lo] of Cw columns, 3 = VDA_PIECES_TRIPLE [hi | lo | hi],
+// 4 = VDA_PIECES_PAIRS (every 32 columns stored as [hi 32 | lo 32]).  c = first of four consecutive operand columns, c % 4 == 0.
+constexpr int PIECES_PLANES = 2, PIECES_TRIPLE = 3, PIECES_PAIRS = 4;
+__host__ __device__ __forceinline__ int pieces_form(int layout) { return layout == VDA_PIECES_PAIRS ? PIECES_PAIRS : PIECES_TRIPLE; }
+__host__ __device__ __forceinline__ int pieces_width(int form, int Cw) { return form == PIECES_TRIPLE ? 3 * Cw : 2 * Cw; }
+template <typename T, bool NT = false>
+__device__ __forceinline__ void store_pieces(T* row, int c, int Cw, int form, typename Vec<T>::v4 hi, typename Vec<T>::v4 lo) {
+    typedef typename Vec<T>::v4 v4;
+    T* p0 = form == PIECES_PAIRS ? row + ((c >> 5) << 6) + (c & 31) : row + c;
+    T* p1 = form == PIECES_PAIRS ? p0 + 32 : p0 + Cw;
+    if (NT) {
+        __builtin_nontemporal_store(hi, reinterpret_cast<v4*>(p0));
+        __builtin_nontemporal_store(lo, reinterpret_cast<v4*>(p1));
+        if (form == PIECES_TRIPLE) __builtin_nontemporal_store(hi, reinterpret_cast<v4*>(p0 + 2 * Cw));
+    } else {
+        *reinterpret_cast<v4*>(p0) = hi;
+        *reinterpret_cast<v4*>(p1) = lo;
+        if (form == PIECES_TRIPLE) *reinterpret_cast<v4*>(p0 + 2 * Cw) = hi;
+    }
+}
+
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }

@@ -107,7 +107,9 @@ __device__ __forceinline__ u32x4 blend2<bf16>(const u32x4& a, const u32x4& b, fl
     return __builtin_bit_cast(u32x4, o);
 }
 
-template <int TN, int TPS, bool RELU_IN, bool UP, int SPEC, typename T>
+// PAIRS (VdaGemmArgs.ab_pairs): a 64-column channel slice is [hi 32 | lo 32] of 32 operand channels, in the map and in the
+// weights; a tap multiplies W_lo A_hi + W_hi A_lo + W_hi A_hi from one halo slice and one read of each fragment.
+template <int TN, int TPS, bool RELU_IN, bool UP, int SPEC, typename T, bool PAIRS = false>
 __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs pa, const int tiles_x, const int tiles_y, const int parked) {
     const VdaGemmArgs p = epi_spec_args<SPEC, T>(pa);          // the epilogue's choices as constants (EPI_SPEC_*)
     typedef typename Vec<T>::v8 frag_t;
@@ -336,6 +338,29 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
             const int tap = tg * TPS + t_in;
             const int dy = tap / 3, dx = tap - dy * 3;
             const int toff = dy * HALO_W + dx;
+            if constexpr (PAIRS) {
+                constexpr int JH = TN > 4 ? 2 : 1, JN = TN / JH;      // channel tiles in halves: fragments of 8 tiles x 2 pieces would not fit
+#pragma unroll
+                for (int jh = 0; jh < JH; ++jh) {
+                    frag_t wf[2][JN];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int j = 0; j < JN; ++j) wf[ks][j] = *reinterpret_cast<const frag_t*>(wb + t_in * N * 128 + w_off[jh * JN + j][ks]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int hp = hbase[i] + toff;
+                        const frag_t a_hi = *reinterpret_cast<const frag_t*>(halo + hp * 128 + ((fq ^ (hp & 7)) << 4));
+                        const frag_t a_lo = *reinterpret_cast<const frag_t*>(halo + hp * 128 + (((4 + fq) ^ (hp & 7)) << 4));
+#pragma unroll
+                        for (int j = 0; j < JN; ++j) acc[i][jh * JN + j] = mfma16(wf[1][j], a_hi, acc[i][jh * JN + j]);
+#pragma unroll
+                        for (int j = 0; j < JN; ++j) acc[i][jh * JN + j] = mfma16(wf[0][j], a_lo, acc[i][jh * JN + j]);
+#pragma unroll
+                        for (int j = 0; j < JN; ++j) acc[i][jh * JN + j] = mfma16(wf[0][j], a_hi, acc[i][jh * JN + j]);
+                    }
+                }
+            } else
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (ks == 1 && half) continue;
@@ -424,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     }
 }
 
-template <int TN, int TPS, bool RELU_IN, bool UP, int SPEC, typename T>
+template <int TN, int TPS, bool RELU_IN, bool UP, int SPEC, typename T, bool PAIRS = false>
 int launch_cfg(const VdaGemmArgs& a, hipStream_t s) {
     const int tiles_x = (a.out_w + PT_W - 1) / PT_W, tiles_y = (a.out_h + PT_H - 1) / PT_H;
     const int imgs = a.M / (a.out_h * a.out_w);
@@ -433,23 +458,27 @@ int launch_cfg(const VdaGemmArgs& a, hipStream_t s) {
     // horizontal scale <= 0.9, vertical <= 1.  fp16 maps only: the bf16 blend converts every value and needs the registers
     // that form leaves to the four-tap loader.
     const int parked = UP && a.ab_type == VDA_T_F16 && 10L * (a.up_w - 1) <= 9L * (a.in_w - 1) && a.up_h <= a.in_h;
-    auto k = conv3_direct_kernel<TN, TPS, RELU_IN, UP, SPEC, T>;
+    auto k = conv3_direct_kernel<TN, TPS, RELU_IN, UP, SPEC, T, PAIRS>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(imgs * tiles_x * tiles_y), a.N / (TN * 16)), dim3(256), lds, s, a, tiles_x, tiles_y, parked);
     return hip_rc(hipGetLastError());
 }
 
-template <bool RELU_IN, bool UP, int SPEC, typename T>
+template <bool RELU_IN, bool UP, int SPEC, typename T, bool PAIRS = false>
 int launch_r(const VdaGemmArgs& a, hipStream_t s) {
-    if (a.N % 128 == 0) return launch_cfg<8, 1, RELU_IN, UP, SPEC, T>(a, s);
-    if (a.N == 64) return launch_cfg<4, 3, RELU_IN, UP, SPEC, T>(a, s);
-    return launch_cfg<2, 3, RELU_IN, UP, SPEC, T>(a, s);
+    if (a.N % 128 == 0) return launch_cfg<8, 1, RELU_IN, UP, SPEC, T, PAIRS>(a, s);
+    if (a.N == 64) return launch_cfg<4, 3, RELU_IN, UP, SPEC, T, PAIRS>(a, s);
+    return launch_cfg<2, 3, RELU_IN, UP, SPEC, T, PAIRS>(a, s);
 }
 
 // the forms the DPT head uses get an epilogue of their own (EPI_SPEC_*); anything else takes the general one
 template <typename T>
 int launch_t(const VdaGemmArgs& a, hipStream_t s) {
     const int spec = epi_spec_of(a);
+    if (a.ab_pairs) {         // fp32 mode: no fused resampling or pre-activation (vda_gemm has checked); fp32 outputs
+        if (spec == EPI_SPEC_DOT) return launch_r<false, false, EPI_SPEC_DOT, T, true>(a, s);
+        return launch_r<false, false, EPI_SPEC_GENERAL, T, true>(a, s);
+    }
     if (a.up_h > 0) {
         if (a.relu_in) return launch_r<true, true, EPI_SPEC_GENERAL, T>(a, s);
         if (spec == EPI_SPEC_OWN) return launch_r<false, true, EPI_SPEC_OWN, T>(a, s);

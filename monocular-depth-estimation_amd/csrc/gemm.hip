@@ -12,7 +12,9 @@
 
 namespace vda {
 
-template <int BM, int BN, int WM, int WN, int AMODE, int SPEC, typename T>
+// PAIRS (VdaGemmArgs.ab_pairs): a K step of 64 stored columns is [hi 32 | lo 32] of 32 operand columns, for A and W alike;
+// the step multiplies W_lo A_hi + W_hi A_lo + W_hi A_hi from one copy and one fragment read of each piece.
+template <int BM, int BN, int WM, int WN, int AMODE, int SPEC, typename T, bool PAIRS = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const VdaGemmArgs p, const GemmTiles gt) {
     constexpr int TM = BM / WM / 16;      // 16x16 MFMA tiles per wave along M
     constexpr int TN = BN / WN / 16;
@@ -108,6 +110,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const VdaGemmArgs p,
         if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
         const char* abuf = smem + cur * (A_BYTES + B_BYTES);
         const char* bbuf = abuf + A_BYTES;
+        if constexpr (PAIRS) {
+            frag_t af[2][TM], wf[2][TN];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const frag_t*>(abuf + tile_off(wm * (BM / WM) + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const frag_t*>(bbuf + tile_off(wn * (BN / WN) + j * 16 + frow, ks * 4 + fq));
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)          // the two small terms first, then hi * hi
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = mfma16(wf[term == 0][j], af[term == 1][i], acc[i][j]);
+        } else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             frag_t af[TM], wf[TN];
@@ -140,12 +159,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const VdaGemmArgs p,
 
 namespace {
 
-template <int BM, int BN, int WM, int WN, int AMODE, int SPEC, typename T>
+template <int BM, int BN, int WM, int WN, int AMODE, int SPEC, typename T, bool PAIRS = false>
 int launch_k(const VdaGemmArgs& a, hipStream_t s) {
     GemmTiles gt{(a.M + BM - 1) / BM, (a.N + BN - 1) / BN};
     const int lds = 2 * (BM + BN) * 128;
     dim3 grid(gt.tiles_m * gt.tiles_n);
-    auto k = gemm_kernel<BM, BN, WM, WN, AMODE, SPEC, T>;
+    auto k = gemm_kernel<BM, BN, WM, WN, AMODE, SPEC, T, PAIRS>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, s, a, gt);
     return hip_rc(hipGetLastError());
@@ -155,6 +174,16 @@ int launch_k(const VdaGemmArgs& a, hipStream_t s) {
 template <int BM, int BN, int WM, int WN, typename T>
 int launch_t(const VdaGemmArgs& a, hipStream_t s) {
     const int spec = epi_spec_of(a);
+    if (a.ab_pairs) {         // the fp32 mode's forms only
+#define VDA_CASE_P(MODE, SPEC) case SPEC: return launch_k<BM, BN, WM, WN, MODE, SPEC, T, true>(a, s);
+        if (a.a_mode == VDA_A_CONV3) return launch_k<BM, BN, WM, WN, VDA_A_CONV3, EPI_SPEC_GENERAL, T, true>(a, s);
+        switch (spec) {
+            VDA_CASE_P(VDA_A_LINEAR, EPI_SPEC_F32) VDA_CASE_P(VDA_A_LINEAR, EPI_SPEC_F32_RES32)
+            VDA_CASE_P(VDA_A_LINEAR, EPI_SPEC_SPLIT) VDA_CASE_P(VDA_A_LINEAR, EPI_SPEC_SPLIT_GELU)
+            default: return launch_k<BM, BN, WM, WN, VDA_A_LINEAR, EPI_SPEC_GENERAL, T, true>(a, s);
+        }
+#undef VDA_CASE_P
+    }
 #define VDA_CASE(MODE, SPEC) case SPEC: return launch_k<BM, BN, WM, WN, MODE, SPEC, T>(a, s);
     if (a.a_mode == VDA_A_CONV3) {
         switch (spec) {
@@ -220,12 +249,14 @@ int check_args(const VdaGemmArgs* args) {
     // split output, whose GELU is the exact form
     if ((a.act == VDA_ACT_GELU || a.epi == VDA_EPI_GEGLU) && a.out_type == VDA_T_F32 && !a.split_out) return VDA_ESHAPE;
     if (a.split_out) {
-        if (a.split_out != 2 && a.split_out != 3) return VDA_EINVAL;
+        if (a.split_out < 2 || a.split_out > 4) return VDA_EINVAL;
         if (!(a.split_scale > 0.f)) return VDA_EINVAL;
         if (a.a_mode != VDA_A_LINEAR || a.epi != VDA_EPI_PLAIN || a.gamma || a.resid_type != VDA_T_NONE || a.row_stat || a.out16) return VDA_ESHAPE;
         if (a.act == VDA_ACT_RELU) return VDA_ESHAPE;
-        if (a.N % 64 != 0 || a.ldc % 8 != 0 || a.ldc < a.split_out * a.N || ((uintptr_t)a.out & 15) != 0) return VDA_ESHAPE;
+        if (a.N % 64 != 0 || a.ldc % 8 != 0 || a.ldc < (a.split_out == 3 ? 3 : 2) * a.N || ((uintptr_t)a.out & 15) != 0) return VDA_ESHAPE;
     }
+    if (a.ab_pairs != 0 && a.ab_pairs != 1) return VDA_EINVAL;
+    if (a.ab_pairs && (a.relu_in || a.row_stat || a.out16 || a.cin_used || a.up_h)) return VDA_ESHAPE;
     if (a.ab_type != VDA_T_BF16 && a.ab_type != VDA_T_F16) return VDA_EINVAL;
     if (a.tile_cfg < 0 || a.tile_cfg > 3) return VDA_EINVAL;
     // folded LayerNorm: consumer side (row_stat / w_colsum) and producer side (out16 / row_part)

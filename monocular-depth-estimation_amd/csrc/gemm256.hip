@@ -125,8 +125,10 @@ __device__ __forceinline__ void epilogue_res32_dma(const VdaGemmArgs& p, f32x4 (
     static_assert(12 + 3 * S <= 63, "vmcnt is a 6-bit counter");
 }
 
-// SPEC: the epilogue specialisation (EPI_SPEC_*, gemm_common.h)
-template <int AMODE, bool RELU_IN, int SPEC, typename T>
+// SPEC: the epilogue specialisation (EPI_SPEC_*, gemm_common.h).  PAIRS (VdaGemmArgs.ab_pairs): the 64 stored columns of a K-tile
+// are [hi 32 | lo 32] of 32 operand columns, so the two k-steps' fragments of a phase are the hi and the lo pieces and a quadrant
+// issues 24 MFMAs (W_lo A_hi + W_hi A_lo + W_hi A_hi) on the copies and fragment reads that serve 16 in the plain form.
+template <int AMODE, bool RELU_IN, int SPEC, typename T, bool PAIRS = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const GemmTiles gt) {
     typedef typename Vec<T>::v8 frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -235,12 +237,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const
     };
     auto quadrant = [&](int a, int b, frag_t (&bf)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (PAIRS) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int term = 0; term < 3; ++term)          // the two small terms first, then hi * hi
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[a * 4 + i][b * 2 + j] = mfma16(bf[j][ks], af[i][ks], acc[a * 4 + i][b * 2 + j]);
+                    for (int j = 0; j < 2; ++j)
+                        acc[a * 4 + i][b * 2 + j] = mfma16(bf[j][term == 0], af[i][term == 1], acc[a * 4 + i][b * 2 + j]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a * 4 + i][b * 2 + j] = mfma16(bf[j][ks], af[i][ks], acc[a * 4 + i][b * 2 + j]);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -315,16 +327,26 @@ int launch_t(const VdaGemmArgs& a, hipStream_t s) {
     GemmTiles gt{(a.M + 255) / 256, (a.N + 255) / 256};
     const int lds = 8 * REGION;
     dim3 grid(gt.tiles_m * gt.tiles_n);
-#define VDA_LAUNCH256(MODE, RELU, SPEC)                                                                              \
+#define VDA_LAUNCH256P(MODE, RELU, SPEC, PAIRS)                                                                      \
     do {                                                                                                             \
-        auto k = gemm256_kernel<MODE, RELU, SPEC, T>;                                                                \
+        auto k = gemm256_kernel<MODE, RELU, SPEC, T, PAIRS>;                                                         \
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
         hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a, gt);                                                       \
     } while (0)
+#define VDA_LAUNCH256(MODE, RELU, SPEC) VDA_LAUNCH256P(MODE, RELU, SPEC, false)
     // specialised epilogues where the model spends its time; everything else takes the general one
     const int spec = epi_spec_of(a);
 #define VDA_CASE256(MODE, RELU, SPEC) case SPEC: VDA_LAUNCH256(MODE, RELU, SPEC); break;
-    if (a.a_mode == VDA_A_CONV3 && a.relu_in) {
+#define VDA_CASE256P(MODE, SPEC) case SPEC: VDA_LAUNCH256P(MODE, false, SPEC, true); break;
+    if (a.ab_pairs && a.a_mode == VDA_A_CONV3) {
+        VDA_LAUNCH256P(VDA_A_CONV3, false, EPI_SPEC_GENERAL, true);
+    } else if (a.ab_pairs) {          // the fp32 mode's forms only
+        switch (spec) {
+            VDA_CASE256P(VDA_A_LINEAR, EPI_SPEC_F32) VDA_CASE256P(VDA_A_LINEAR, EPI_SPEC_F32_RES32)
+            VDA_CASE256P(VDA_A_LINEAR, EPI_SPEC_SPLIT) VDA_CASE256P(VDA_A_LINEAR, EPI_SPEC_SPLIT_GELU)
+            default: VDA_LAUNCH256P(VDA_A_LINEAR, false, EPI_SPEC_GENERAL, true);
+        }
+    } else if (a.a_mode == VDA_A_CONV3 && a.relu_in) {
         switch (spec) {
             VDA_CASE256(VDA_A_CONV3, true, EPI_SPEC_OWN_RELU) VDA_CASE256(VDA_A_CONV3, true, EPI_SPEC_OWN_RES)
             default: VDA_LAUNCH256(VDA_A_CONV3, true, EPI_SPEC_GENERAL);
@@ -350,7 +372,9 @@ int launch_t(const VdaGemmArgs& a, hipStream_t s) {
         }
     }
 #undef VDA_CASE256
+#undef VDA_CASE256P
 #undef VDA_LAUNCH256
+#undef VDA_LAUNCH256P
     return hip_rc(hipGetLastError());
 }
 

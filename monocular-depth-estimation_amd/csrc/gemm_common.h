@@ -286,21 +286,15 @@ __device__ __forceinline__ void gemm_epilogue_staged(const VdaGemmArgs& p, f32x4
                     // four fp32 values -> their scaled 16-bit pieces, stored at the same columns of each segment of the row
                     if (mm < p.M && out_n0 + col < n_out) {
                         const f32x4 f = __builtin_bit_cast(f32x4, v) * split_scale;
-                        char* dst = reinterpret_cast<char*>(p.out) + ((size_t)mm * p.ldc + out_n0 + col) * 2;
-                        const size_t seg = (size_t)p.N * 2;
                         if (p.ab_type == VDA_T_F16) {
                             note_saturation(sat_flag, f);
                             f16x4 hi, lo;
                             split4<f16>(f, hi, lo);
-                            __builtin_nontemporal_store(hi, reinterpret_cast<f16x4*>(dst));
-                            __builtin_nontemporal_store(lo, reinterpret_cast<f16x4*>(dst + seg));
-                            if (p.split_out == 3) __builtin_nontemporal_store(hi, reinterpret_cast<f16x4*>(dst + 2 * seg));
+                            store_pieces<f16, true>(reinterpret_cast<f16*>(p.out) + (size_t)mm * p.ldc, out_n0 + col, p.N, p.split_out, hi, lo);
                         } else {
                             bf16x4 hi, lo;
                             split4<bf16>(f, hi, lo);
-                            __builtin_nontemporal_store(hi, reinterpret_cast<bf16x4*>(dst));
-                            __builtin_nontemporal_store(lo, reinterpret_cast<bf16x4*>(dst + seg));
-                            if (p.split_out == 3) __builtin_nontemporal_store(hi, reinterpret_cast<bf16x4*>(dst + 2 * seg));
+                            store_pieces<bf16, true>(reinterpret_cast<bf16*>(p.out) + (size_t)mm * p.ldc, out_n0 + col, p.N, p.split_out, hi, lo);
                         }
                     }
                     continue;

@@ -6,14 +6,14 @@
 
 namespace {
 
-// One wave per row, C <= 64 * 4 * VEC4 floats.  C % 4 == 0.  SPLIT (16-bit T): the output row is 3 C wide, the
-// [hi | lo | hi] pieces of split_scale * y (the fp32 mode's GEMM operand, see vda_split3).
+// One wave per row, C <= 64 * 4 * VEC4 floats.  C % 4 == 0.  SPLIT (16-bit T): the output row holds the pieces of
+// split_scale * y in the form `split_form` (the fp32 mode's GEMM operand, see vda_split3 and store_pieces).
 template <int VEC4, typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, T* __restrict__ out,
                                                         const float* __restrict__ w, const float* __restrict__ b, int rows,
                                                         int C, float eps, int rows_per_group, int in_group, int in_skip,
                                                         const float* __restrict__ pe, int pe_hw, int pe_T,
-                                                        float split_scale = 0.f, int* sat_flag = nullptr) {
+                                                        float split_scale = 0.f, int split_form = 0, int* sat_flag = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     const float rstd = rsqrtf(wave_sum(q) / C + eps);
     const float* per = pe ? pe + (size_t)((row / pe_hw) % pe_T) * C : nullptr;
-    T* orow = out + (size_t)row * C * (SPLIT ? 3 : 1);
+    T* orow = out + (size_t)row * (SPLIT ? pieces_width(split_form, C) : C);
 #pragma unroll
     for (int i = 0; i < VEC4; ++i) {
         const int c = (i * 64 + lane) * 4;
@@ -58,9 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 note_saturation_as(sat_flag, y, T{});
                 typename Vec<T>::v4 hi, lo;
                 split4<T>(y, hi, lo);
-                *reinterpret_cast<typename Vec<T>::v4*>(orow + c) = hi;
-                *reinterpret_cast<typename Vec<T>::v4*>(orow + C + c) = lo;
-                *reinterpret_cast<typename Vec<T>::v4*>(orow + 2 * C + c) = hi;
+                store_pieces<T>(orow, c, C, split_form, hi, lo);
             } else {
                 const typename Vec<T>::v4 o = {(T)y[0], (T)y[1], (T)y[2], (T)y[3]};
                 *reinterpret_cast<typename Vec<T>::v4*>(orow + c) = o;
@@ -221,7 +219,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
 
 extern "C" int vda_layernorm(const float* x, void* out, const float* weight, const float* bias, int rows, int C, float eps,
                              int rows_per_group, int in_group, int in_skip, const float* pe, int pe_hw, int pe_T,
-                             int out_type, float split_scale, int* sat_flag, void* stream) {
+                             int out_type, float split_scale, int split_layout, int* sat_flag, void* stream) {
     if (!x || !out || !weight || !bias || rows <= 0 || C <= 0) return VDA_EINVAL;
     if (C % 4 != 0 || C > 2048 || rows_per_group <= 0 || in_group < rows_per_group + in_skip) return VDA_ESHAPE;
     if (pe && (pe_hw <= 0 || pe_T <= 0)) return VDA_EINVAL;
@@ -229,25 +227,27 @@ extern "C" int vda_layernorm(const float* x, void* out, const float* weight, con
     const bool split = split_scale != 0.f;
     if (split && (!(split_scale > 0.f) || out_type == VDA_T_F32)) return VDA_EINVAL;
     if (split && C % 64 != 0) return VDA_ESHAPE;
+    if (split && split_layout != VDA_PIECES_TRIPLE && split_layout != VDA_PIECES_PAIRS) return VDA_EINVAL;
+    const int form = pieces_form(split_layout);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((rows + 3) / 4), block(256);
 #define LN_LAUNCH(V)                                                                                                       \
     do {                                                                                                                   \
         if (split && out_type == VDA_T_F16)                                                                                \
             hipLaunchKernelGGL((layernorm_kernel<V, f16, true>), grid, block, 0, s, x, reinterpret_cast<f16*>(out), weight, bias, \
-                               rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T, split_scale, sat_flag);   \
+                               rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T, split_scale, form, sat_flag);   \
         else if (split)                                                                                                    \
             hipLaunchKernelGGL((layernorm_kernel<V, bf16, true>), grid, block, 0, s, x, reinterpret_cast<bf16*>(out), weight, bias, \
-                               rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T, split_scale, sat_flag);   \
+                               rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T, split_scale, form, sat_flag);   \
         else if (out_type == VDA_T_F16)                                                                                         \
             hipLaunchKernelGGL((layernorm_kernel<V, f16>), grid, block, 0, s, x, reinterpret_cast<f16*>(out), weight, bias, \
-                               rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T, 0.f, nullptr);            \
+                               rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T, 0.f, 0, nullptr);            \
         else if (out_type == VDA_T_F32)                                                                                    \
             hipLaunchKernelGGL((layernorm_kernel<V, float>), grid, block, 0, s, x, reinterpret_cast<float*>(out), weight,  \
-                               bias, rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T, 0.f, nullptr);      \
+                               bias, rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T, 0.f, 0, nullptr);      \
         else                                                                                                               \
             hipLaunchKernelGGL((layernorm_kernel<V, bf16>), grid, block, 0, s, x, reinterpret_cast<bf16*>(out), weight,    \
-                               bias, rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T, 0.f, nullptr);      \
+                               bias, rows, C, eps, rows_per_group, in_group, in_skip, pe, pe_hw, pe_T, 0.f, 0, nullptr);      \
     } while (0)
     if (C <= 256) LN_LAUNCH(1);
     else if (C <= 512) LN_LAUNCH(2);

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
 // One workgroup per 4 rows; 32-bit index arithmetic inside a row.
 template <typename T>
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, T* __restrict__ out, long rows, int C,
-                                                     int ldx, int Cp, int act, float scale, int* sat_flag) {
+                                                     int ldx, int Cp, int act, float scale, int form, int* sat_flag) {
     const long row0 = (long)blockIdx.x * 4;
     const int cv = Cp / 4;
     for (int i = threadIdx.x; i < 4 * cv; i += 256) {
@@ -197,10 +197,7 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
         }
         note_saturation_as(sat_flag, v, T{});
         split4<T>(v, hi, lo);
-        T* o = out + row * (3L * Cp) + c;
-        *reinterpret_cast<typename Vec<T>::v4*>(o) = hi;
-        *reinterpret_cast<typename Vec<T>::v4*>(o + Cp) = lo;
-        *reinterpret_cast<typename Vec<T>::v4*>(o + 2 * Cp) = hi;
+        store_pieces<T>(out + row * (long)pieces_width(form, Cp), c, Cp, form, hi, lo);
     }
 }
 
@@ -258,20 +255,22 @@ extern "C" int vda_im2col_patch14(const float* x, void* out, int frames, int H, 
 }
 
 extern "C" int vda_split3(const float* x, void* out, long rows, int C, int ldx, int Cp, int act, int out_type, float scale,
-                          int* sat_flag, void* stream) {
+                          int layout, int* sat_flag, void* stream) {
     if (!x || !out || rows <= 0 || C <= 0) return VDA_EINVAL;
     if (act < VDA_SPLIT_NONE || act > VDA_SPLIT_GEGLU) return VDA_EINVAL;
     if ((out_type != VDA_T_BF16 && out_type != VDA_T_F16) || !(scale > 0.f)) return VDA_EINVAL;
+    if (layout != VDA_PIECES_TRIPLE && layout != VDA_PIECES_PAIRS) return VDA_EINVAL;
+    const int form = pieces_form(layout);
     const int in_cols = act == VDA_SPLIT_GEGLU ? 2 * C : C;
     if (C % 4 != 0 || Cp % 64 != 0 || Cp < C || ldx < in_cols || ldx % 4 != 0 || (rows + 3) / 4 > 0x7fffffffL) return VDA_ESHAPE;
     if (act == VDA_SPLIT_GEGLU && C % 16 != 0) return VDA_ESHAPE;
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (out_type == VDA_T_F16)
         hipLaunchKernelGGL(split3_kernel<f16>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                           reinterpret_cast<f16*>(out), rows, C, ldx, Cp, act, scale, sat_flag);
+                           reinterpret_cast<f16*>(out), rows, C, ldx, Cp, act, scale, form, sat_flag);
     else
         hipLaunchKernelGGL(split3_kernel<bf16>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                           reinterpret_cast<bf16*>(out), rows, C, ldx, Cp, act, scale, sat_flag);
+                           reinterpret_cast<bf16*>(out), rows, C, ldx, Cp, act, scale, form, sat_flag);
     return hip_rc(hipGetLastError());
 }
 

@@ -17,7 +17,7 @@ import warnings
 import torch
 
 from . import hip
-from .packing import ACT_SPLIT_SCALE, MIN_ACT_SPLIT_SCALE, SPLIT_DTYPE, SplitWeight
+from .packing import ACT_SPLIT_SCALE, MIN_ACT_SPLIT_SCALE, PIECES_PAIRS, SPLIT_DTYPE, SplitWeight
 from .spec import TEMPORAL_HEADS
 
 BF16 = torch.bfloat16
@@ -27,9 +27,9 @@ def _empty(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
-class Triple:
-    """Marks a 16-bit matrix [rows, 3K] that already holds the [hi | lo | hi] pieces of an fp32 operand (written by the kernel
-    that produced the values), so that ``Engine.operand`` does not split it again."""
+class Pieces:
+    """Marks a 16-bit matrix that already holds the hi/lo pieces of an fp32 operand in the engine's layout (written by the
+    kernel that produced the values), so that ``Engine.operand`` does not split it again."""
 
     def __init__(self, t):
         self.t = t
@@ -58,6 +58,8 @@ class Engine:
         # fp32 storage: the producers write the 16-bit pieces of their fp32 results themselves (LayerNorm, the QKV and fc1
         # products, attention) instead of an fp32 matrix that a vda_split3 pass then reads; False keeps the separate passes
         self.fused_split = SPLIT_DTYPE == torch.float16
+        self.layout = packed.layout                       # of the operand pieces (packing.PIECES_*); the weights are packed alike
+        self.pw = 2 if self.layout == PIECES_PAIRS else 3    # stored columns per operand column
         self.encoder_streams = 2      # frame groups of the encoder that run on concurrent streams (see encoder())
         self.side_streams = []
         self.head_streams = 2         # 2: parts of the head run on the first side stream beside the rest (see head())
@@ -75,7 +77,7 @@ class Engine:
     def operand(self, a, relu=False, act=None):
         """The MFMA operand of activation matrix ``a`` [rows, K]: itself, or its bf16 [hi | lo | hi] split in fp32 mode
         (``act``: an activation the split applies first; GEGLU halves the width)."""
-        if isinstance(a, Triple):
+        if isinstance(a, Pieces):
             assert act is None and not relu
             return a.t, False
         if not self.split:
@@ -84,14 +86,15 @@ class Engine:
         rows, K = a.shape
         if act == hip.SPLIT_GEGLU:
             K //= 2
-        a3 = _empty((rows, 3 * K), SPLIT_DTYPE, self.dev)
-        hip.split3(a, a3, rows, K, a.stride(0), K, relu=relu, act=act, scale=self.act_scale, sat_flag=self.sat)
+        a3 = _empty((rows, self.pw * K), SPLIT_DTYPE, self.dev)
+        hip.split3(a, a3, rows, K, a.stride(0), K, relu=relu, act=act, scale=self.act_scale, sat_flag=self.sat, layout=self.layout)
         return a3, False
 
     def weight(self, w, kw):
         """The device tensor of a packed weight; for the fp32 mode's scaled hi/lo pieces also sets the GEMM's ``acc_scale``."""
         if isinstance(w, SplitWeight):
             kw["acc_scale"] = 1.0 / (w.scale * self.act_scale)
+            kw["ab_pairs"] = w.layout == PIECES_PAIRS
             return w.t
         return w
 
@@ -149,9 +152,9 @@ class Engine:
         the other frames of its window, and consecutive windows of a video share ten of 32 frames, video_depth.py:157-164)."""
         w, dev = self.w, self.dev
         hw = (H // 14) * (W // 14)
-        # (fp32 head: the tap norms write the operand pieces of the head's first products directly, see Triple)
+        # (fp32 head: the tap norms write the operand pieces of the head's first products directly, see Pieces)
         self.taps_split = self.split_head and self.fused_split
-        taps = [_empty((frames * hw, 3 * w.D), SPLIT_DTYPE, dev) if self.taps_split else _empty((frames * hw, w.D), self.hdt, dev)
+        taps = [_empty((frames * hw, self.pw * w.D), SPLIT_DTYPE, dev) if self.taps_split else _empty((frames * hw, w.D), self.hdt, dev)
                 for _ in w.taps]
         first = 0
         if carried is not None:
@@ -210,13 +213,15 @@ class Engine:
         hip.assemble_tokens(tok, w.cls, w.pos_table(hp, wp), xs, frames, hw, D)
         del cols, tok
         pieces = self.split and self.fused_split       # fp32 storage with the operand pieces written by the producers
-        tap_kw = dict(split_scale=self.act_scale, sat_flag=self.sat) if self.taps_split else {}
+        S = dict(split_scale=self.act_scale, sat_flag=self.sat)
+        LN = dict(split_layout=self.layout, **S)
+        tap_kw = LN if self.taps_split else {}
         if pieces:
-            S = dict(split_scale=self.act_scale, sat_flag=self.sat)
-            y = _empty((M, 3 * D), SPLIT_DTYPE, dev)         # [hi | lo | hi] of the normed rows
-            qkv = _empty((M, 6 * D), SPLIT_DTYPE, dev)       # [hi | lo] of q, k, v
-            att = _empty((M, 3 * D), SPLIT_DTYPE, dev)
-            hid = _empty((M, 12 * D), SPLIT_DTYPE, dev)      # [hi | lo | hi] of GELU(fc1)
+            pw = self.pw
+            y = _empty((M, pw * D), SPLIT_DTYPE, dev)        # the pieces of the normed rows
+            qkv = _empty((M, 6 * D), SPLIT_DTYPE, dev)       # [hi | lo] planes of q, k, v
+            att = _empty((M, pw * D), SPLIT_DTYPE, dev)
+            hid = _empty((M, pw * 4 * D), SPLIT_DTYPE, dev)  # the pieces of GELU(fc1)
         else:
             y = _empty((M, D), self.edt, dev)
             qkv = _empty((M, 3 * D), self.edt, dev)
@@ -248,13 +253,13 @@ class Engine:
                     self.linear(hid, b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D, out16=y, row_part=part)
                     hip.rowstats_finish(part, stat, M, slots, 1e-6)
             elif pieces:
-                hip.layernorm(xs, y, b["ln1_w"], b["ln1_b"], M, D, 1e-6, **S)
-                self.linear(Triple(y), b["wqkv"], qkv, b["bqkv"], split_out=2, **S)
-                hip.attention_pairs(qkv, att, frames, N, heads, self.act_scale)
-                self.linear(Triple(att), b["wproj"], xs, b["bproj"], resid=xs, ldr=D)
-                hip.layernorm(xs, y, b["ln2_w"], b["ln2_b"], M, D, 1e-6, **S)
-                self.linear(Triple(y), b["wfc1"], hid, b["bfc1"], act=hip.ACT_GELU, split_out=3, **S)      # the exact GELU
-                self.linear(Triple(hid), b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D)
+                hip.layernorm(xs, y, b["ln1_w"], b["ln1_b"], M, D, 1e-6, **LN)
+                self.linear(Pieces(y), b["wqkv"], qkv, b["bqkv"], split_out=2, **S)
+                hip.attention_pairs(qkv, att, frames, N, heads, self.act_scale, out_layout=self.layout)
+                self.linear(Pieces(att), b["wproj"], xs, b["bproj"], resid=xs, ldr=D)
+                hip.layernorm(xs, y, b["ln2_w"], b["ln2_b"], M, D, 1e-6, **LN)
+                self.linear(Pieces(y), b["wfc1"], hid, b["bfc1"], act=hip.ACT_GELU, split_out=4 if pw == 2 else 3, **S)      # the exact GELU
+                self.linear(Pieces(hid), b["wfc2"], xs, b["bfc2"], resid=xs, ldr=D)
             else:
                 hip.layernorm(xs, y, b["ln1_w"], b["ln1_b"], M, D, 1e-6)
                 self.linear(y, b["wqkv"], qkv, b["bqkv"])
@@ -286,7 +291,8 @@ class Engine:
         self.linear(g, m["in_w"], hs, m["in_b"])
         pieces = self.split and self.fused_split
         if pieces:      # fp32 storage: the norms write the operand pieces of the products that follow them
-            n, ln_kw = Triple(_empty((M, 3 * C), SPLIT_DTYPE, dev)), dict(split_scale=self.act_scale, sat_flag=self.sat)
+            n = Pieces(_empty((M, self.pw * C), SPLIT_DTYPE, dev))
+            ln_kw = dict(split_scale=self.act_scale, sat_flag=self.sat, split_layout=self.layout)
             n_out = n.t
         else:
             n, ln_kw = g, {}                             # reuse as the normed-activation buffer
@@ -337,7 +343,7 @@ class Engine:
         proj = []
         for i in range(4):
             p = _empty((frames * hw, w.ocp[i]), self.hdt, dev)
-            self.linear(Triple(taps[i]) if self.taps_split else taps[i], w.proj_w[i], p, w.proj_b[i])
+            self.linear(Pieces(taps[i]) if self.taps_split else taps[i], w.proj_w[i], p, w.proj_b[i])
             proj.append(p)
         # The four pyramid branches are independent until the fusion blocks join them, the coarsest first.  The coarsest
         # branch (stride-2 conv, temporal module, fusion block, temporal module: 19 x 19 and 37 x 37 maps, grids that fill a

@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
         ("ct_h", C.c_int), ("ct_w", C.c_int), ("ct_k", C.c_int), ("ct_c", C.c_int), ("tile_cfg", C.c_int),
         ("up_h", C.c_int), ("up_w", C.c_int), ("acc_scale", C.c_float), ("cin_used", C.c_int),
         ("out16", C.c_void_p), ("row_part", C.c_void_p), ("ld16", C.c_int), ("row_stat", C.c_void_p), ("w_colsum", C.c_void_p),
-        ("split_out", C.c_int), ("split_scale", C.c_float), ("sat_flag", C.c_void_p),
+        ("split_out", C.c_int), ("split_scale", C.c_float), ("sat_flag", C.c_void_p), ("ab_pairs", C.c_int),
     ]
 
 
@@ -57,9 +57,9 @@ def lib():
         l.vda_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
         l.vda_gemm_kernel_choice.argtypes = [C.POINTER(GemmArgs)]
         l.vda_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        l.vda_attention_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        l.vda_attention_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         l.vda_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
-                                    C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+                                    C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
         l.vda_round_rowstats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         l.vda_rowstats_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
         l.vda_groupnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -70,7 +70,7 @@ def lib():
         l.vda_bilinear_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         l.vda_im2col_patch14.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.vda_split3.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
-                                 C.c_void_p, C.c_void_p]
+                                 C.c_int, C.c_void_p, C.c_void_p]
         l.vda_assemble_tokens.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]
         l.vda_temporal_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                              C.c_int, C.c_void_p]
@@ -143,7 +143,7 @@ def zero_page(device):
 def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr=0, resid2=None, ldr2=0, act=ACT_NONE,
          epi=EPI_PLAIN, relu_in=False, conv=None, convt=None, dot_w=None, dot_b=0.0, tile_cfg=None, upsample_from=None,
          acc_scale=1.0, cin_used=0, out16=None, row_part=None, row_stat=None, w_colsum=None, split_out=0, split_scale=1.0,
-         sat_flag=None):
+         sat_flag=None, ab_pairs=False):
     """Enqueue one vda_gemm.  ``conv`` = (in_h, in_w, cin, out_h, out_w, stride); ``convt`` = (h, w, k, c);
     ``upsample_from`` = (h, w) of the map ``a`` that is bilinearly resampled to in_h x in_w on the fly;
     ``acc_scale`` multiplies every sum before the epilogue (operands pre-scaled by powers of two); ``cin_used``: only the
@@ -151,8 +151,9 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
     Folded LayerNorm: ``out16`` [M, >= N] (a's type) and ``row_part`` fp32 [M, N // 64, 2] make the product also emit its
     output rows rounded to 16 bits with their partial sums; ``row_stat`` fp32 [M, 2] and ``w_colsum`` fp32 [N] make it
     normalise its sums with the (mean, rstd) of the rows of ``a`` (see VdaGemmArgs in include/vda_hip.h).
-    ``split_out`` = 2 / 3 (fp32 mode): ``out`` is 16-bit [M, >= split_out * N] and receives the [hi | lo] / [hi | lo | hi] pieces of
-    ``split_scale`` times the result; ``sat_flag`` (one int32 on the device) is set when a scaled value leaves the half range."""
+    ``split_out`` (fp32 mode): ``out`` is 16-bit and receives the pieces of ``split_scale`` times the result, 2 = planes [hi | lo]
+    (2N columns), 3 = PIECES_TRIPLE (3N), 4 = PIECES_PAIRS (2N); ``sat_flag`` (one int32 on the device) is set when a scaled
+    value leaves the half range.  ``ab_pairs``: a and w hold PIECES_PAIRS (K, lda and cin count stored columns)."""
     _dev(a, w, out, bias, gamma, resid, resid2, dot_w, out16, row_part, row_stat, w_colsum, sat_flag)
     g = GemmArgs()
     g.a, g.w, g.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -166,6 +167,7 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
     g.act, g.epi, g.relu_in = act, epi, int(bool(relu_in))
     g.acc_scale = float(acc_scale)
     g.cin_used = int(cin_used)
+    g.ab_pairs = int(bool(ab_pairs))
     g.tile_cfg = TILE_CFG if tile_cfg is None else tile_cfg
     if a.dtype != w.dtype:
         raise TypeError("vda_gemm: a and w must share one 16-bit type")
@@ -190,7 +192,7 @@ def gemm(a, w, out, *, M, N, K, lda, ldc, bias=None, gamma=None, resid=None, ldr
     g.out_type = T_F32 if split_out else _type(out)
     g.resid_type = T_NONE if resid is None else _type(resid)
     n_res = N // 2 if epi == EPI_GEGLU else N
-    n_out = max(split_out, 1) * n_res
+    n_out = {0: 1, 2: 2, 3: 3, 4: 2}[split_out] * n_res
     _need("vda_gemm", sat_flag=(sat_flag, 1), w=(w, N * K), gamma=(gamma, N), dot_w=(dot_w, N), w_colsum=(w_colsum, N), row_stat=(row_stat, 2 * M),
           row_part=(row_part, 2 * M * (N // 64)), out16=(out16, (M - 1) * (out16.stride(0) if out16 is not None else 0) + N),
           a=(a if conv is None else None, (M - 1) * lda + K), bias=(bias if convt is None else None, N),
@@ -273,34 +275,44 @@ def attention(qkv, out, frames, n_tok, heads):
     _check(lib().vda_attention(_ptr(qkv), _ptr(out), frames, n_tok, heads, _type(qkv), _stream()), "vda_attention")
 
 
-def attention_pairs(qkv2, out3, frames, n_tok, heads, scale):
-    """vda_attention_pairs: fp16 [hi | lo] pieces of scale * qkv in, fp16 [hi | lo | hi] pieces of scale * output out."""
+PIECES_TRIPLE, PIECES_PAIRS = 0, 1          # VDA_PIECES_*
+
+
+def pieces_width(layout, K):
+    return 2 * K if layout == PIECES_PAIRS else 3 * K
+
+
+def attention_pairs(qkv2, out3, frames, n_tok, heads, scale, out_layout=PIECES_TRIPLE):
+    """vda_attention_pairs: fp16 [hi | lo] planes of scale * qkv in, fp16 pieces of scale * output out (``out_layout``)."""
     _dev(qkv2, out3)
     if qkv2.dtype != torch.float16 or out3.dtype != torch.float16:
         raise TypeError("vda_attention_pairs: IEEE-half pieces in and out")
-    _need("vda_attention_pairs", qkv2=(qkv2, frames * n_tok * 6 * heads * 64), out3=(out3, frames * n_tok * 3 * heads * 64))
-    _check(lib().vda_attention_pairs(_ptr(qkv2), _ptr(out3), frames, n_tok, heads, float(scale), _stream()), "vda_attention_pairs")
+    _need("vda_attention_pairs", qkv2=(qkv2, frames * n_tok * 6 * heads * 64),
+          out3=(out3, frames * n_tok * pieces_width(out_layout, heads * 64)))
+    _check(lib().vda_attention_pairs(_ptr(qkv2), _ptr(out3), frames, n_tok, heads, float(scale), int(out_layout), _stream()),
+           "vda_attention_pairs")
 
 
 SPLIT_NONE, SPLIT_RELU, SPLIT_GELU, SPLIT_GEGLU = 0, 1, 2, 3
 
 
-def split3(x, out, rows, Cdim, ldx, Cp, relu=False, act=None, scale=1.0, sat_flag=None):
-    """fp32 [rows][ldx] -> 16-bit [rows][3*Cp] segments [hi | lo | hi] of ``scale * x`` in ``out``'s type (bf16 or fp16): the
-    A operand of the fp32 mode's GEMMs, after the activation ``act`` (SPLIT_*; ``relu=True`` is SPLIT_RELU)."""
+def split3(x, out, rows, Cdim, ldx, Cp, relu=False, act=None, scale=1.0, sat_flag=None, layout=PIECES_TRIPLE):
+    """fp32 [rows][ldx] -> the 16-bit pieces of ``scale * x`` in ``out``'s type (bf16 or fp16), [rows][3*Cp] as [hi | lo | hi]
+    (PIECES_TRIPLE) or [rows][2*Cp] with every 32 columns as [hi 32 | lo 32] (PIECES_PAIRS): the A operand of the fp32 mode's
+    GEMMs, after the activation ``act`` (SPLIT_*; ``relu=True`` is SPLIT_RELU)."""
     _dev(x, out, sat_flag)
     if act is None:
         act = SPLIT_RELU if relu else SPLIT_NONE
     if sat_flag is not None and sat_flag.dtype != torch.int32:
         raise TypeError("vda_split3: sat_flag is one int32")
-    _need("vda_split3", x=(x, (rows - 1) * ldx + (2 * Cdim if act == SPLIT_GEGLU else Cdim)), out=(out, rows * 3 * Cp))
-    _check(lib().vda_split3(_ptr(x), _ptr(out), rows, Cdim, ldx, Cp, int(act), _type(out), float(scale), _ptr(sat_flag), _stream()),
-           "vda_split3")
+    _need("vda_split3", x=(x, (rows - 1) * ldx + (2 * Cdim if act == SPLIT_GEGLU else Cdim)), out=(out, rows * pieces_width(layout, Cp)))
+    _check(lib().vda_split3(_ptr(x), _ptr(out), rows, Cdim, ldx, Cp, int(act), _type(out), float(scale), int(layout), _ptr(sat_flag),
+                            _stream()), "vda_split3")
 
 
 def layernorm(x, out, weight, bias, rows, Cdim, eps, rows_per_group=None, in_group=None, in_skip=0, pe=None, pe_hw=1, pe_T=1,
-              split_scale=0.0, sat_flag=None):
-    """``split_scale`` != 0: ``out`` is 16-bit [rows, 3 * Cdim], the [hi | lo | hi] pieces of split_scale * LayerNorm(x)."""
+              split_scale=0.0, sat_flag=None, split_layout=PIECES_TRIPLE):
+    """``split_scale`` != 0: ``out`` holds the 16-bit pieces of split_scale * LayerNorm(x) in ``split_layout``."""
     _dev(x, out, weight, bias, pe, sat_flag)
     if sat_flag is not None and sat_flag.dtype != torch.int32:
         raise TypeError("vda_layernorm: sat_flag is one int32")
@@ -308,10 +320,10 @@ def layernorm(x, out, weight, bias, rows, Cdim, eps, rows_per_group=None, in_gro
         rows_per_group = in_group = rows
     groups = -(-rows // rows_per_group)
     last = (groups - 1) * in_group + in_skip + (rows - 1 - (groups - 1) * rows_per_group)       # the last input row read
-    _need("vda_layernorm", x=(x, (last + 1) * Cdim), out=(out, rows * Cdim * (3 if split_scale else 1)), weight=(weight, Cdim),
+    _need("vda_layernorm", x=(x, (last + 1) * Cdim), out=(out, rows * (pieces_width(split_layout, Cdim) if split_scale else Cdim)), weight=(weight, Cdim),
           bias=(bias, Cdim), pe=(pe, pe_T * Cdim), sat_flag=(sat_flag, 1))
     _check(lib().vda_layernorm(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), rows, Cdim, eps, rows_per_group, in_group,
-                               in_skip, _ptr(pe), pe_hw, pe_T, _type(out), float(split_scale), _ptr(sat_flag), _stream()),
+                               in_skip, _ptr(pe), pe_hw, pe_T, _type(out), float(split_scale), int(split_layout), _ptr(sat_flag), _stream()),
            "vda_layernorm")
 
 

@@ -10,6 +10,7 @@ Everything here runs once per (weights, device): it is preparation, not the per-
   * biases, LayerScale, norm parameters and the temporal position tables stay fp32.
 """
 import math
+import os
 
 ATTENTION_Q_SCALE = math.log2(math.e) / 8.0      # VDA_ATTENTION_Q_SCALE of the C header
 
@@ -72,16 +73,23 @@ ACT_SPLIT_SCALE = 16.0           # power of two every fp32 activation is multipl
 #                                  values down to 2^-7 keep a normal low half, values up to 4094 fit the high half
 
 
+# layout of an fp32 operand's 16-bit pieces along K (VDA_PIECES_* of the C header): TRIPLE = [hi | lo | hi] against weights
+# [hi | hi | lo], a plain product over 3K columns; PAIRS = every 32 columns stored as [hi 32 | lo 32] on both sides, which the
+# kernels multiply as hi*hi + hi*lo + lo*hi from one copy of each piece (VdaGemmArgs.ab_pairs)
+PIECES_TRIPLE, PIECES_PAIRS = 0, 1
+PIECES_LAYOUT = PIECES_TRIPLE if os.environ.get("VDA_PIECES_LAYOUT", "pairs") == "triple" else PIECES_PAIRS
 MIN_ACT_SPLIT_SCALE = 2.0 ** -8  # the engine lowers the scale by factors of 16 when a value saturates, down to this (values to 1.6e7)
 
 
 class SplitWeight:
-    """A weight matrix packed for the fp32 mode: ``t`` = 16-bit [..., 3K] laid out [hi | hi | lo] along the last axis (the
-    activation side is [hi | lo | hi], see vda_split3), pieces of ``scale * w``; ``scale`` is the power of two that puts
-    the largest |w| just below 2048, so that the low halves are normal IEEE halves."""
+    """A weight matrix packed for the fp32 mode: ``t`` = the 16-bit pieces of ``scale * w`` along the last axis, [..., 3K] laid
+    out [hi | hi | lo] (PIECES_TRIPLE; the activation side is [hi | lo | hi], see vda_split3) or [..., 2K] with every 32
+    columns as [hi 32 | lo 32] (PIECES_PAIRS, both sides alike); ``scale`` is the power of two that puts the largest |w| just
+    below 2048, so that the low halves are normal IEEE halves."""
 
-    def __init__(self, w, dtype=None):
+    def __init__(self, w, dtype=None, layout=None):
         dtype = dtype or SPLIT_DTYPE
+        self.layout = PIECES_LAYOUT if layout is None else layout
         self.scale = 1.0
         if dtype == torch.float16:
             top = float(w.abs().max())
@@ -89,7 +97,14 @@ class SplitWeight:
         ws = w * self.scale
         hi = ws.to(dtype)
         lo = (ws - hi.float()).to(dtype)
-        self.t = torch.cat([hi, hi, lo], dim=-1).contiguous()
+        if self.layout == PIECES_PAIRS:         # [..., K] -> [..., K/32, (hi, lo), 32] -> [..., 2K]
+            K = w.shape[-1]
+            if K % 32:
+                raise ValueError(f"pairs layout: K = {K} is not a multiple of 32")
+            blocks = w.shape[:-1] + (K // 32, 32)
+            self.t = torch.stack([hi.reshape(blocks), lo.reshape(blocks)], dim=-2).reshape(w.shape[:-1] + (2 * K,)).contiguous()
+        else:
+            self.t = torch.cat([hi, hi, lo], dim=-1).contiguous()
 
     @property
     def shape(self):
@@ -117,9 +132,11 @@ class PackedWeights:
     """Device-resident kernel-layout weights of one model.  ``precision`` "fp32" packs every matrix as 16-bit hi/lo triples
     (``SplitWeight``) for the fp32 storage mode (``head_dtype`` is then ignored); see PRECISIONS for the mixed forms."""
 
-    def __init__(self, sd, encoder, features, out_channels, device, head_dtype=torch.float16, precision="half"):
+    def __init__(self, sd, encoder, features, out_channels, device, head_dtype=torch.float16, precision="half", layout=None):
         self.device = device
         self.precision = precision
+        self.layout = PIECES_LAYOUT if layout is None else layout        # of the fp32 mode's operand pieces (PIECES_*)
+        split_weight = lambda t: SplitWeight(t, layout=self.layout)  # noqa: E731
         self.split_enc, self.split_head, self.split_tail = PRECISIONS[precision]
         self.head_dtype = torch.float32 if self.split_head else head_dtype
         self.encoder = encoder

@@ -61,6 +61,8 @@ class VideoDepthAnything(nn.Module):
         # hi/lo products on the same matrix cores (about 2^-21 per product) -- what ``infer_video_depth(fp32=True)``
         # selects, the counterpart of the reference running without autocast (video_depth.py:136).
         self.precision = "half"
+        # fp32 mode: layout of the operand pieces (packing.PIECES_TRIPLE / PIECES_PAIRS); None = the library's default (pairs)
+        self.pieces_layout = None
         gen = torch.Generator().manual_seed(0)
         for key, (shape, kind) in state_dict_spec(encoder, features, self.out_channels, num_frames).items():
             if kind in ("nw",):
@@ -110,7 +112,7 @@ class VideoDepthAnything(nn.Module):
         if self._flat is None:
             self._flat = list(self.state_dict(keep_vars=True).values())
         p = self.pretrained.cls_token
-        return (p.device, self.head_dtype, tuple((t.data_ptr(), t._version) for t in self._flat))
+        return (p.device, self.head_dtype, self.pieces_layout, tuple((t.data_ptr(), t._version) for t in self._flat))
 
     def _ensure_engine(self):
         dev = self.pretrained.cls_token.device
@@ -123,7 +125,7 @@ class VideoDepthAnything(nn.Module):
         cached = self._engines.get(self.precision)
         if cached is None or cached[0] != key:
             packed = PackedWeights(self.state_dict(), self.encoder, self.features, self.out_channels, dev, self.head_dtype,
-                                   precision=self.precision)
+                                   precision=self.precision, layout=self.pieces_layout)
             cached = (key, Engine(packed))
             self._engines[self.precision] = cached
         return cached[1]

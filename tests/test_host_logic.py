@@ -220,16 +220,16 @@ def test_gemm_argument_struct_matches_the_header():
     """hip.GemmArgs mirrors VdaGemmArgs field by field: compile the header and compare size and the offsets of the last fields."""
     import ctypes
     import tempfile
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "vda_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", ' \
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "vda_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", ' \
           'sizeof(VdaGemmArgs), offsetof(VdaGemmArgs, acc_scale), offsetof(VdaGemmArgs, out16), offsetof(VdaGemmArgs, ld16), ' \
-          'offsetof(VdaGemmArgs, w_colsum), offsetof(VdaGemmArgs, split_scale), offsetof(VdaGemmArgs, sat_flag)); return 0; }\n'
+          'offsetof(VdaGemmArgs, w_colsum), offsetof(VdaGemmArgs, split_scale), offsetof(VdaGemmArgs, sat_flag), offsetof(VdaGemmArgs, ab_pairs)); return 0; }\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
         size, *offs = (int(v) for v in subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split())
     G = hip.GemmArgs
     assert ctypes.sizeof(G) == size
-    assert [G.acc_scale.offset, G.out16.offset, G.ld16.offset, G.w_colsum.offset, G.split_scale.offset, G.sat_flag.offset] == offs
+    assert [G.acc_scale.offset, G.out16.offset, G.ld16.offset, G.w_colsum.offset, G.split_scale.offset, G.sat_flag.offset, G.ab_pairs.offset] == offs
 
 
 # ---- stand-ins for the device entry points used by the host pipeline ------------------------------------------------

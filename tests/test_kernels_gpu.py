@@ -42,6 +42,17 @@ OUT_TOL = {torch.bfloat16: BF_OUT, torch.float16: BF_OUT, torch.float32: F32_OUT
 # three-term hi/lo product, relative to the largest output: bf16 pieces 2^-16 per operand pair; IEEE-half pieces 2^-21,
 # where the bound is set by the fp32 accumulation over K
 SPLIT_TOL = {torch.bfloat16: 6e-5, torch.float16: 2e-6}
+LAYOUTS = [hip.PIECES_TRIPLE, hip.PIECES_PAIRS]
+
+
+def hi_lo_of(pieces, K, layout):
+    """(hi, lo) [rows, K] of a matrix of operand pieces in either layout."""
+    if layout == hip.PIECES_PAIRS:
+        b = pieces.reshape(pieces.shape[0], K // 32, 2, 32)
+        return b[:, :, 0].reshape(-1, K), b[:, :, 1].reshape(-1, K)
+    return pieces[:, :K], pieces[:, K:2 * K]
+
+
 
 
 def test_library_loads_and_reports_version():
@@ -616,9 +627,9 @@ def test_stitch_kernels():
     assert torch.allclose(out, torch.clamp(x * ss[0] + ss[1], min=0), rtol=1e-6, atol=1e-6)
 
 
-def split_w(w, piece):
+def split_w(w, piece, layout=0):
     from video_depth_anything.packing import SplitWeight
-    return SplitWeight(w, piece)
+    return SplitWeight(w, piece, layout)
 
 
 ACT_SCALE = {torch.bfloat16: 1.0, torch.float16: 16.0}     # what the engine multiplies activations by before the split
@@ -652,22 +663,29 @@ def test_split3_half_pieces_saturate_instead_of_overflowing():
     assert out[0, 2].item() + out[0, 64 + 2].item() == 70000.0        # the low half takes up the excess
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("piece", HALVES)
 @pytest.mark.parametrize("cfg", TILE_CFGS)
-@pytest.mark.parametrize("M,N,K", [(1370, 1024, 1024), (300, 192, 384)])
-def test_gemm_fp32_mode_three_term_product(M, N, K, cfg, piece):
+@pytest.mark.parametrize("M,N,K", [(1370, 1024, 1024), (300, 192, 384), (500, 64, 64), (260, 32, 128)])
+def test_gemm_fp32_mode_three_term_product(M, N, K, cfg, piece, layout):
     """fp32 operands through vda_split3 / split weights: close to an fp64 product, ~100x (bf16 pieces) or ~3000x (IEEE-half
     pieces, operands scaled by powers of two and the sums scaled back) closer than one 16-bit pass."""
     a, w = rnd((M, K), 1, 1.0, torch.float32), rnd((N, K), 2, 1 / math.sqrt(K), torch.float32)
     bias = rnd((N,), 3, 0.1, torch.float32)
-    a3 = torch.empty((M, 3 * K), dtype=piece, device=DEV)
-    hip.split3(a, a3, M, K, K, K, scale=ACT_SCALE[piece])
+    Ks = hip.pieces_width(layout, K)
+    a3 = torch.empty((M, Ks), dtype=piece, device=DEV)
+    hip.split3(a, a3, M, K, K, K, scale=ACT_SCALE[piece], layout=layout)
     out = torch.empty((M, N), dtype=torch.float32, device=DEV)
-    sw = split_w(w, piece)
-    kw = dict(M=M, N=N, K=3 * K, lda=3 * K, ldc=N, bias=bias, tile_cfg=cfg, acc_scale=1.0 / (sw.scale * ACT_SCALE[piece]))
+    sw = split_w(w, piece, layout)
+    kw = dict(M=M, N=N, K=Ks, lda=Ks, ldc=N, bias=bias, tile_cfg=cfg, acc_scale=1.0 / (sw.scale * ACT_SCALE[piece]),
+              ab_pairs=layout == hip.PIECES_PAIRS)
     hip.gemm(a3, sw.t, out, **kw)
     want = (a.double() @ w.double().t() + bias.double()).float()
     close(out, want, SPLIT_TOL[piece], "three-term gemm")
+    r = rnd((M, N), 4, 1.0, torch.float32)
+    res = r.clone()
+    hip.gemm(a3, sw.t, res, resid=res, ldr=N, **kw)                      # the residual-stream form, in place
+    close(res, want + r, SPLIT_TOL[piece], "three-term gemm with an fp32 residual")
     with pytest.raises(RuntimeError):            # the epilogue's GELU is for 16-bit outputs; fp32 callers use vda_split3's
         hip.gemm(a3, sw.t, out, act=hip.ACT_GELU, **kw)
 
@@ -710,20 +728,24 @@ def test_gemm_gelu_polynomial_accuracy():
         assert (err <= 5.4e-5 + 2.0 ** -11 * want.abs() + 1e-7).all(), err.max()
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cout", [128, 64, 32])
 @pytest.mark.parametrize("piece", HALVES)
-def test_conv3x3_fp32_mode(piece):
-    B, h, w_, cin, cout = 2, 19, 13, 64, 128
+def test_conv3x3_fp32_mode(piece, cout, cfg, layout):
+    B, h, w_, cin = 2, 19, 45, 64
     x = rnd((B, cin, h, w_), 1, 1.0, torch.float32)
     wt = rnd((cout, cin, 3, 3), 2, 1 / math.sqrt(9 * cin), torch.float32)
     bias = rnd((cout,), 3, 0.1, torch.float32)
     want = F.conv2d(F.relu(x).double(), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1).float()
     a = x.permute(0, 2, 3, 1).contiguous().reshape(B * h * w_, cin)
-    a3 = torch.empty((B * h * w_, 3 * cin), dtype=piece, device=DEV)
-    hip.split3(a, a3, B * h * w_, cin, cin, cin, relu=True, scale=ACT_SCALE[piece])
-    wg = split_w(wt.permute(0, 2, 3, 1).contiguous(), piece).reshape(cout, 27 * cin)
+    cs = hip.pieces_width(layout, cin)
+    a3 = torch.empty((B * h * w_, cs), dtype=piece, device=DEV)
+    hip.split3(a, a3, B * h * w_, cin, cin, cin, relu=True, scale=ACT_SCALE[piece], layout=layout)
+    wg = split_w(wt.permute(0, 2, 3, 1).contiguous(), piece, layout).reshape(cout, 9 * cs)
     out = torch.empty((B, h, w_, cout), dtype=torch.float32, device=DEV)
-    hip.gemm(a3, wg.t, out, M=B * h * w_, N=cout, K=27 * cin, lda=0, ldc=cout, bias=bias, conv=(h, w_, 3 * cin, h, w_, 1),
-             acc_scale=1.0 / (wg.scale * ACT_SCALE[piece]))
+    hip.gemm(a3, wg.t, out, M=B * h * w_, N=cout, K=9 * cs, lda=0, ldc=cout, bias=bias, conv=(h, w_, cs, h, w_, 1),
+             acc_scale=1.0 / (wg.scale * ACT_SCALE[piece]), tile_cfg=cfg, ab_pairs=layout == hip.PIECES_PAIRS)
     close(out, want, SPLIT_TOL[piece], "three-term conv3x3")
 
 
@@ -746,83 +768,101 @@ def pieces_of(ref, piece=torch.float16):
     return hi, lo
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("piece", HALVES)
 @pytest.mark.parametrize("rows,C", [(2740, 1024), (100, 384), (37, 64)])
-def test_layernorm_writes_operand_pieces(rows, C, piece):
+def test_layernorm_writes_operand_pieces(rows, C, piece, layout):
     """vda_layernorm with split_scale: the rows vda_split3 would make of the fp32 result, bit for bit."""
     x = rnd((rows, C), 1, 2.0, torch.float32) + 0.3
     w, b = rnd((C,), 2, 0.3, torch.float32) + 1.0, rnd((C,), 3, 0.2, torch.float32)
     y = torch.empty((rows, C), dtype=torch.float32, device=DEV)
     hip.layernorm(x, y, w, b, rows, C, 1e-6)
-    want = torch.empty((rows, 3 * C), dtype=piece, device=DEV)
-    hip.split3(y, want, rows, C, C, C, scale=ACT_SCALE[piece])
-    got = torch.full((rows, 3 * C), float("nan"), dtype=piece, device=DEV)
+    width = hip.pieces_width(layout, C)
+    want = torch.empty((rows, width), dtype=piece, device=DEV)
+    hip.split3(y, want, rows, C, C, C, scale=ACT_SCALE[piece], layout=layout)
+    hi, lo = hi_lo_of(want, C, layout)
+    assert torch.equal(hi.float(), (y * ACT_SCALE[piece]).to(piece).float()) and torch.equal(lo.float(), (y * ACT_SCALE[piece] - hi.float()).to(piece).float())
+    got = torch.full((rows, width), float("nan"), dtype=piece, device=DEV)
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
-    hip.layernorm(x, got, w, b, rows, C, 1e-6, split_scale=ACT_SCALE[piece], sat_flag=flag)
+    hip.layernorm(x, got, w, b, rows, C, 1e-6, split_scale=ACT_SCALE[piece], sat_flag=flag, split_layout=layout)
     assert torch.equal(got, want) and int(flag.item()) == 0
-    hip.layernorm(x, got, w * 4000.0, b, rows, C, 1e-6, split_scale=ACT_SCALE[piece], sat_flag=flag)      # |y| up to ~1.6e4
+    hip.layernorm(x, got, w * 4000.0, b, rows, C, 1e-6, split_scale=ACT_SCALE[piece], sat_flag=flag, split_layout=layout)      # |y| up to ~1.6e4
     assert int(flag.item()) == (1 if piece == torch.float16 else 0) and bool(torch.isfinite(got.float()).all())
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("cfg", [1, 2])
 @pytest.mark.parametrize("piece", HALVES)
 @pytest.mark.parametrize("M,N,K,segs,gelu", [(1370, 3072, 1024, 2, False), (333, 1536, 384, 3, True), (300, 4096, 1024, 3, True),
                                               (40, 192, 64, 3, False), (700, 64, 128, 2, False)])
-def test_gemm_writes_its_output_as_operand_pieces(M, N, K, segs, gelu, piece, cfg):
+def test_gemm_writes_its_output_as_operand_pieces(M, N, K, segs, gelu, piece, cfg, layout):
     """VdaGemmArgs.split_out: the three-term product's result (with the exact GELU where asked) stored as the [hi | lo] or
     [hi | lo | hi] pieces of split_scale * v instead of an fp32 matrix: what vda_split3 makes of the fp32 output of the same
     product, up to the summation-order-free arithmetic both share (bit for bit without GELU; with it, both evaluate the same
-    erf form on the same sums)."""
+    erf form on the same sums).  ``layout``: of the operands AND of the output (segs = 2 always writes the two planes that
+    vda_attention_pairs reads); with PIECES_PAIRS the product runs in the kernels' three-products-per-K-step form."""
     if cfg == 2 and N < 192:
         pytest.skip("the 256x256 tile is not offered for narrow outputs")
     sc = ACT_SCALE[piece]
+    pairs = layout == hip.PIECES_PAIRS
     a, w = rnd((M, K), 1, 1.0, torch.float32), rnd((N, K), 2, 1 / math.sqrt(K), torch.float32)
     bias = rnd((N,), 3, 0.1, torch.float32)
-    a3 = torch.empty((M, 3 * K), dtype=piece, device=DEV)
-    hip.split3(a, a3, M, K, K, K, scale=sc)
-    sw = split_w(w, piece)
-    kw = dict(M=M, N=N, K=3 * K, lda=3 * K, bias=bias, tile_cfg=cfg, acc_scale=1.0 / (sw.scale * sc))
+    Ks = hip.pieces_width(layout, K)
+    a3 = torch.empty((M, Ks), dtype=piece, device=DEV)
+    hip.split3(a, a3, M, K, K, K, scale=sc, layout=layout)
+    sw = split_w(w, piece, layout)
+    kw = dict(M=M, N=N, K=Ks, lda=Ks, bias=bias, tile_cfg=cfg, acc_scale=1.0 / (sw.scale * sc), ab_pairs=pairs)
     plain = torch.empty((M, N), dtype=torch.float32, device=DEV)
     hip.gemm(a3, sw.t, plain, ldc=N, **kw)
-    want = torch.empty((M, 3 * N), dtype=piece, device=DEV)
-    hip.split3(plain, want, M, N, N, N, act=hip.SPLIT_GELU if gelu else hip.SPLIT_NONE, scale=sc)
-    ld = segs * N + 64                                      # a row stride beyond the segments
+    form = 2 if segs == 2 else (4 if pairs else 3)
+    out_layout = hip.PIECES_TRIPLE if segs == 2 else layout       # (the first two segments of a triple are the two planes)
+    width = 2 * N if form != 3 else 3 * N
+    want = torch.empty((M, hip.pieces_width(out_layout, N)), dtype=piece, device=DEV)
+    hip.split3(plain, want, M, N, N, N, act=hip.SPLIT_GELU if gelu else hip.SPLIT_NONE, scale=sc, layout=out_layout)
+    ld = width + 64                                         # a row stride beyond the pieces
     got = torch.full((M, ld), float("nan"), dtype=piece, device=DEV)
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
-    hip.gemm(a3, sw.t, got, ldc=ld, act=hip.ACT_GELU if gelu else hip.ACT_NONE, split_out=segs, split_scale=sc, sat_flag=flag, **kw)
+    hip.gemm(a3, sw.t, got, ldc=ld, act=hip.ACT_GELU if gelu else hip.ACT_NONE, split_out=form, split_scale=sc, sat_flag=flag, **kw)
+    g_hi, g_lo = hi_lo_of(got[:, :width], N, out_layout)
+    w_hi, w_lo = hi_lo_of(want, N, out_layout)
     if gelu:        # the same erf form on the same sums, but compiled into two kernels: equal up to a fused multiply-add or two
-        sum_got, sum_want = got[:, :N].float() + got[:, N:2 * N].float(), want[:, :N].float() + want[:, N:2 * N].float()
+        sum_got, sum_want = g_hi.float() + g_lo.float(), w_hi.float() + w_lo.float()
         assert (sum_got - sum_want).abs().max() <= SPLIT_TOL[piece] * sum_want.abs().max()
-        if segs == 3:
+        if form == 3:
             assert torch.equal(got[:, :N], got[:, 2 * N:3 * N])
     else:
-        assert torch.equal(got[:, :segs * N], want[:, :segs * N])
-    assert bool(torch.isnan(got[:, segs * N:].float()).all()) and int(flag.item()) == 0
+        assert torch.equal(got[:, :width], want[:, :width])
+    assert bool(torch.isnan(got[:, width:].float()).all()) and int(flag.item()) == 0
     exact = a.double() @ w.double().t() + bias.double()
+    close(plain, exact.float(), SPLIT_TOL[piece], "three-term product")
     exact = F.gelu(exact) if gelu else exact
-    close((got[:, :N].float() + got[:, N:2 * N].float()) / sc, exact.float(), SPLIT_TOL[piece], "pieces of the product")
+    close((g_hi.float() + g_lo.float()) / sc, exact.float(), SPLIT_TOL[piece], "pieces of the product")
     if piece == torch.float16:      # a scaled value beyond the half range sets the flag, and only then
-        hip.gemm(a3, sw.t, got, ldc=ld, split_out=segs, split_scale=sc * 2.0 ** 16, sat_flag=flag, **kw)
-        assert int(flag.item()) == 1 and bool(torch.isfinite(got[:, :segs * N].float()).all())
+        hip.gemm(a3, sw.t, got, ldc=ld, split_out=form, split_scale=sc * 2.0 ** 16, sat_flag=flag, **kw)
+        assert int(flag.item()) == 1 and bool(torch.isfinite(got[:, :width].float()).all())
     with pytest.raises(RuntimeError):            # no residual form
-        hip.gemm(a3, sw.t, got, ldc=ld, split_out=segs, split_scale=sc, resid=plain, ldr=N, **kw)
+        hip.gemm(a3, sw.t, got, ldc=ld, split_out=form, split_scale=sc, resid=plain, ldr=N, **kw)
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("frames,n_tok,heads", [(2, 1370, 2), (1, 129, 3), (2, 36, 1), (1, 700, 16)])
-def test_attention_on_operand_pieces(frames, n_tok, heads):
+def test_attention_on_operand_pieces(frames, n_tok, heads, layout):
     """vda_attention_pairs: [hi | lo] pieces of 16 * qkv in, [hi | lo | hi] pieces of 16 * output out, against fp64."""
     D, sc = heads * 64, 16.0
     qkv = rnd((frames, n_tok, 3 * D), 1, 1.0, torch.float32)
     qkv[..., :D] *= 0.35
     hi, lo = pieces_of(qkv * sc)
     qkv2 = torch.cat([hi, lo], dim=-1).contiguous()
-    out3 = torch.full((frames, n_tok, 3 * D), float("nan"), dtype=torch.float16, device=DEV)
-    hip.attention_pairs(qkv2, out3, frames, n_tok, heads, sc)
+    out3 = torch.full((frames * n_tok, hip.pieces_width(layout, D)), float("nan"), dtype=torch.float16, device=DEV)
+    hip.attention_pairs(qkv2, out3, frames, n_tok, heads, sc, out_layout=layout)
     q, k, v = qkv.double().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
     want = (softmax2(q @ k.transpose(-1, -2)) @ v).transpose(1, 2).reshape(frames, n_tok, D).float()
-    got = (out3[..., :D].float() + out3[..., D:2 * D].float()) / sc
+    hi, lo = hi_lo_of(out3, D, layout)
+    got = ((hi.float() + lo.float()) / sc).reshape(frames, n_tok, D)
     close(got, want, 3e-6, "attention on pieces")
-    assert torch.equal(out3[..., :D], out3[..., 2 * D:])
+    assert bool(torch.isfinite(out3.float()).all())
+    if layout == hip.PIECES_TRIPLE:
+        assert torch.equal(out3[:, :D], out3[:, 2 * D:])
     old = torch.empty((frames, n_tok, D), dtype=torch.float32, device=DEV)
     hip.attention(qkv, old, frames, n_tok, heads)
     close(got, old, 2e-6, "against the fp32-in / fp32-out form")

@@ -186,6 +186,96 @@ def test_forward_fp32_mode_matches_reference_goldens(golden_dir, vits, name, sha
     assert mr <= FP32_MODE_MAX_REL and ar <= FP32_MODE_MAX_REL
 
 
+def test_fp32_mode_forms_agree(golden_dir, vits):
+    """The fp32 storage mode's variants against each other and the goldens: operand pieces as pairs (the default: three
+    products per K step from one copy of each piece) or triples (a plain product over 3K columns), written by the producing
+    kernels or by separate split passes."""
+    model, _ = vits
+    from video_depth_anything.packing import PIECES_PAIRS, PIECES_TRIPLE
+    g = np.load(os.path.join(golden_dir, "g4_forward.npz"))
+    x = torch.from_numpy(np.random.RandomState(41).standard_normal((1, 32, 3, 70, 98)).astype(np.float32)).cuda()
+    outs = {}
+    try:
+        model.precision = "fp32"
+        for layout in (PIECES_PAIRS, PIECES_TRIPLE):
+            model.pieces_layout = layout
+            eng = model._ensure_engine()
+            assert eng.layout == layout
+            for fused in (True, False):
+                eng.fused_split = fused
+                out = model(x).cpu().numpy()
+                mr, ar = report(f"fp32 mode, layout {layout}, producer-written pieces {fused}", out, g["T32"])
+                assert mr <= FP32_MODE_MAX_REL and ar <= FP32_MODE_MAX_REL
+                outs[(layout, fused)] = out
+            eng.fused_split = True
+    finally:
+        model.precision, model.pieces_layout = "half", None
+    ref = outs[(PIECES_TRIPLE, False)]
+    for k, o in outs.items():
+        assert np.abs(o - ref).max() <= 1e-5 * np.abs(ref).max(), k
+
+
+# ---- activation ranges of trained checkpoints ("outliers" weight profile) ------------------------------------------------------
+@pytest.fixture(scope="module")
+def vits_outliers():
+    sd = {k: torch.from_numpy(v) for k, v in spec.synth_state_dict(**spec.MODEL_CONFIGS["vits"], seed=1, profile="outliers").items()}
+    m = VideoDepthAnything(**spec.MODEL_CONFIGS["vits"])
+    m.load_state_dict(sd, strict=True)
+    return m.to("cuda").eval()
+
+
+OUTLIER_CASES = [("T32", (1, 32, 3, 70, 98), 41), ("B2T3", (2, 3, 3, 56, 42), 43)]
+
+
+@pytest.mark.parametrize("name,shape,seed", OUTLIER_CASES)
+def test_forward_with_checkpoint_like_outliers_in_16_bit_mode(golden_dir, vits_outliers, name, shape, seed):
+    """A few residual-stream channels at +-300 .. 3000, LayerScale factors up to 10 and a head channel at 5.5e4 (near the end of
+    the IEEE-half range): the 16-bit mode stays finite and within the stated bounds (bf16 encoder operands have fp32's range;
+    the fp16 head's outputs saturate at 65504 instead of overflowing)."""
+    g = np.load(os.path.join(golden_dir, "g4c_forward_outliers.npz"))
+    x = torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32)).cuda()
+    out = vits_outliers(x).cpu().numpy()
+    assert np.isfinite(out).all()
+    mr, ar = report(f"outliers {name}, 16-bit mode", out, g[name])
+    assert mr <= MAX_REL and ar <= ABS_REL
+
+
+def test_forward_with_checkpoint_like_outliers_in_fp32_mode_lowers_the_operand_scale(golden_dir, vits_outliers):
+    """fp32 storage mode: with the default operand scale (16) the head channel at 5.5e4 leaves the range of the IEEE-half
+    pieces.  The kernel that splits it raises the saturation flag; the engine warns, divides the scale by 16 and computes the
+    window again: the result meets the fp32 mode's bound, and the lower scale is kept for the following windows."""
+    g = np.load(os.path.join(golden_dir, "g4c_forward_outliers.npz"))
+    m = vits_outliers
+    m.precision = "fp32"
+    try:
+        eng = m._ensure_engine()
+        eng.act_scale = 16.0
+        name, shape, seed = OUTLIER_CASES[0]
+        x = torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32)).cuda()
+        with pytest.warns(RuntimeWarning, match="operand scale"):
+            out = m(x).cpu().numpy()
+        assert eng.act_scale == 1.0 and int(eng.sat.item()) == 0
+        mr, ar = report(f"outliers {name}, fp32 mode", out, g[name])
+        assert mr <= FP32_MODE_MAX_REL and ar <= FP32_MODE_MAX_REL
+        import warnings
+        name, shape, seed = OUTLIER_CASES[1]
+        x = torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32)).cuda()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                       # no further warning: the scale already fits
+            out = m(x).cpu().numpy()
+        mr, ar = report(f"outliers {name}, fp32 mode", out, g[name])
+        assert mr <= FP32_MODE_MAX_REL and ar <= FP32_MODE_MAX_REL
+        # a value no operand scale holds: a clear error instead of a silently saturated result
+        from video_depth_anything.engine import SaturationError
+        from video_depth_anything.packing import MIN_ACT_SPLIT_SCALE
+        eng.act_scale = MIN_ACT_SPLIT_SCALE
+        with pytest.raises(SaturationError):
+            m(x * 1e9)
+    finally:
+        m.precision = "half"
+        m._engines.pop("fp32", None)
+
+
 # ---- depth maps with exact zeros and pixels next to the clamp ("clamped" weight profile) --------------------------------------
 # The floored max-relative metric allows a pixel whose reference depth is 0 an absolute error of 1e-2 * 1e-3 * max = 1e-5 of
 # the map's maximum.  The fp32 storage mode meets the stated bounds there (measured 1.0-1.6e-3 / AbsRel 5e-6).  No 16-bit
