@@ -227,6 +227,11 @@ int vda_groupnorm_static(const void* x, void* out, const float* weight, const fl
 int vda_bilinear_nhwc(const void* x, void* out, int frames, int in_h, int in_w, int out_h, int out_w, int C, int dtype,
                       void* stream);
 int vda_bilinear_f32(const float* x, float* out, int frames, int in_h, int in_w, int out_h, int out_w, int relu, void* stream);
+/* vda_bilinear_nhwc on an fp32 map whose result is written as the 16-bit operand pieces of `scale` * v (out_type BF16 or F16,
+ * `layout` VDA_PIECES_*, rows of 3C or 2C columns; C % 64 == 0): the fp32 mode's input of a convolution on a resampled map
+ * (dpt_temporal.py:93-99), which then never exists in fp32.  sat_flag as in vda_split3. */
+int vda_bilinear_nhwc_pieces(const float* x, void* out, int frames, int in_h, int in_w, int out_h, int out_w, int C, int out_type,
+                             float scale, int layout, int* sat_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Patch embedding front end.

@@ -395,6 +395,19 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restr
 // maximum and every product is the three-term sum hi*hi + lo*hi + hi*lo.  Scores carry the factor scale^2 (both operands are
 // scaled), so the running maximum is kept in those units and a probability is exp2(s / scale^2 + log2 P_SCALE): one fused
 // multiply-add in front of the hardware exponential, whose result is already the scaled probability that is split.
+// f16(a - h.lo) into the low half of a register / f16(a - h.hi) into the high half of `d` (the other half is kept): one
+// mixed-precision multiply-add each (fp32 arithmetic on a half-precision operand read in place, one rounding), in place of a
+// conversion to fp32, a subtraction, a conversion back and a pack.
+__device__ __forceinline__ unsigned remainder_to_lo(float a, unsigned h) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(h));
+    return d;
+}
+__device__ __forceinline__ void remainder_to_hi(unsigned& d, float a, unsigned h) {
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(d) : "v"(a), "v"(h));
+}
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(256, 2) void attn_pairs_kernel(const f16* __restrict__ qkv, f16* __restrict__ out, int n_tok, int heads,
                                                             int q_blocks, float s2, int out_form) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 32768];      // per buffer: K hi, K lo, V hi, V lo (8 KiB each)
@@ -503,16 +516,21 @@ __global__ __launch_bounds__(256, 2) void attn_pairs_kernel(const f16* __restric
             }
         }
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
-        f16x8 ph[2][2], pl[2][2];
+        u32x4 ph[2][2], pl[2][2];              // eight halves each: the B operands of the second product
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kbk][i], inv_s2, LOG2_P_SCALE));     // P_SCALE * p <= 2^14
-                ps[i & 3] += pv;
-                const f16 x = (f16)pv;
-                ph[kbk][i >> 3][i & 7] = x;
-                pl[kbk][i >> 3][i & 7] = (f16)(pv - (float)x);
+            for (int i = 0; i < 16; i += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kbk][i], inv_s2, LOG2_P_SCALE));     // P_SCALE * p <= 2^14
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kbk][i + 1], inv_s2, LOG2_P_SCALE));
+                ps[i & 3] += p0;
+                ps[(i + 1) & 3] += p1;
+                const f16x2 hi = {(f16)p0, (f16)p1};                     // one packed conversion
+                const unsigned h = __builtin_bit_cast(unsigned, hi);
+                unsigned l = remainder_to_lo(p0, h);
+                remainder_to_hi(l, p1, h);
+                ph[kbk][i >> 3][(i & 7) >> 1] = h;
+                pl[kbk][i >> 3][(i & 7) >> 1] = l;
             }
         l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 
@@ -530,9 +548,10 @@ __global__ __launch_bounds__(256, 2) void attn_pairs_kernel(const f16* __restric
                     const f16x4 b1 = read_tr_f16(vl + o1);
                     const f16x8 vhi = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                     const f16x8 vlo = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, ph[kbk][s2i], o[db], 0, 0, 0);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, pl[kbk][s2i], o[db], 0, 0, 0);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, ph[kbk][s2i], o[db], 0, 0, 0);
+                    const f16x8 p_hi = __builtin_bit_cast(f16x8, ph[kbk][s2i]), p_lo = __builtin_bit_cast(f16x8, pl[kbk][s2i]);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, p_hi, o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, p_lo, o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, p_hi, o[db], 0, 0, 0);
                 }
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's copies of the next tile have landed

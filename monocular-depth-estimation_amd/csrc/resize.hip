@@ -9,15 +9,26 @@ struct Lerp {
     int i0, i1;
     float w0, w1;
 };
+// (The build contracts a * b + c wherever it finds one, and finds different ones in different kernels.  The rounded product
+// `src` is therefore pinned behind an empty asm, and blend_px below spells its fused multiply-adds out: every kernel that
+// resamples then gives the same bits.)
 __device__ __forceinline__ Lerp lerp_of(int dst, int in, int out) {
     const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
-    const float src = scale * (float)dst;
+    float src = scale * (float)dst;
+    asm volatile("" : "+v"(src));
     Lerp l;
     l.i0 = (int)src;
     l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
     l.w1 = src - (float)l.i0;
     l.w0 = 1.f - l.w1;
     return l;
+}
+
+// The four-tap blend w0y (w0x a + w1x b) + w1y (w0x c + w1x d) in a fixed form: three products, three fused multiply-adds.
+__device__ __forceinline__ float blend_px(const Lerp& ly, const Lerp& lx, float a, float b, float c, float d) {
+    const float top = __builtin_fmaf(lx.w1, b, lx.w0 * a);
+    const float bottom = __builtin_fmaf(lx.w1, d, lx.w0 * c);
+    return __builtin_fmaf(ly.w1, bottom, ly.w0 * top);
 }
 
 // One workgroup per output row (frame, oy): the vertical taps are computed once per workgroup and all per-element index
@@ -43,10 +54,40 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const T* __restrict_
         v8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float v = ly.w0 * (lx.w0 * (float)a[k] + lx.w1 * (float)b[k]) + ly.w1 * (lx.w0 * (float)cc[k] + lx.w1 * (float)d[k]);
-            o[k] = (T)v;
+            o[k] = (T)blend_px(ly, lx, (float)a[k], (float)b[k], (float)cc[k], (float)d[k]);
         }
         *reinterpret_cast<v8*>(orow + (size_t)i * 8) = o;
+    }
+}
+
+// The same resampling of an fp32 map, written as the 16-bit operand pieces of scale * v (fp32 mode: the input of a convolution
+// that runs on the resampled map, which then never exists in fp32).  Four channels per lane and step.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_nhwc_pieces_kernel(const float* __restrict__ x, T* __restrict__ out, int in_h, int in_w,
+                                                                   int out_h, int out_w, int C, float scale, int form, int* sat_flag) {
+    const unsigned cv = C / 4;
+    const int f = blockIdx.x / out_h, oy = blockIdx.x - f * out_h;
+    const Lerp ly = lerp_of(oy, in_h, out_h);
+    const float* row0 = x + ((size_t)f * in_h + ly.i0) * in_w * C;
+    const float* row1 = x + ((size_t)f * in_h + ly.i1) * in_w * C;
+    const int width = pieces_width(form, C);
+    T* orow = out + (size_t)blockIdx.x * out_w * width;
+    const unsigned n = out_w * cv;
+    for (unsigned i = threadIdx.x; i < n; i += 256) {
+        const unsigned ox = i / cv, c = (i - ox * cv) * 4;
+        const Lerp lx = lerp_of((int)ox, in_w, out_w);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(row0 + lx.i0 * C + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(row0 + lx.i1 * C + c);
+        const f32x4 cc = *reinterpret_cast<const f32x4*>(row1 + lx.i0 * C + c);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(row1 + lx.i1 * C + c);
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            v[k] = blend_px(ly, lx, a[k], b[k], cc[k], d[k]) * scale;
+        note_saturation_as(sat_flag, v, T{});
+        typename Vec<T>::v4 hi, lo;
+        split4<T>(v, hi, lo);
+        store_pieces<T>(orow + (size_t)ox * width, (int)c, C, form, hi, lo);
     }
 }
 
@@ -59,7 +100,7 @@ __global__ __launch_bounds__(256) void bilinear_f32_kernel(const float* __restri
     float* orow = out + (size_t)blockIdx.x * out_w;
     for (int ox = threadIdx.x; ox < out_w; ox += 256) {
         const Lerp lx = lerp_of(ox, in_w, out_w);
-        float v = ly.w0 * (lx.w0 * row0[lx.i0] + lx.w1 * row0[lx.i1]) + ly.w1 * (lx.w0 * row1[lx.i0] + lx.w1 * row1[lx.i1]);
+        float v = blend_px(ly, lx, row0[lx.i0], row0[lx.i1], row1[lx.i0], row1[lx.i1]);
         if (relu) v = fmaxf(v, 0.f);
         orow[ox] = v;
     }
@@ -227,6 +268,24 @@ extern "C" int vda_bilinear_nhwc(const void* x, void* out, int frames, int in_h,
     else
         hipLaunchKernelGGL(bilinear_nhwc_kernel<bf16>, grid, dim3(256), 0, s, reinterpret_cast<const bf16*>(x),
                            reinterpret_cast<bf16*>(out), in_h, in_w, out_h, out_w, C);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int vda_bilinear_nhwc_pieces(const float* x, void* out, int frames, int in_h, int in_w, int out_h, int out_w, int C,
+                                        int out_type, float scale, int layout, int* sat_flag, void* stream) {
+    if (!x || !out || frames <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || C <= 0) return VDA_EINVAL;
+    if (C % 64 != 0) return VDA_ESHAPE;
+    if ((out_type != VDA_T_BF16 && out_type != VDA_T_F16) || !(scale > 0.f)) return VDA_EINVAL;
+    if (layout != VDA_PIECES_TRIPLE && layout != VDA_PIECES_PAIRS) return VDA_EINVAL;
+    if ((long)frames * out_h > 0x7fffffffL || (long)out_w * (C / 4) > 0x7fffffffL || (long)in_w * C > 0x7fffffffL) return VDA_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(frames * out_h);
+    if (out_type == VDA_T_F16)
+        hipLaunchKernelGGL(bilinear_nhwc_pieces_kernel<f16>, grid, dim3(256), 0, s, x, reinterpret_cast<f16*>(out), in_h, in_w, out_h,
+                           out_w, C, scale, pieces_form(layout), sat_flag);
+    else
+        hipLaunchKernelGGL(bilinear_nhwc_pieces_kernel<bf16>, grid, dim3(256), 0, s, x, reinterpret_cast<bf16*>(out), in_h, in_w, out_h,
+                           out_w, C, scale, pieces_form(layout), sat_flag);
     return hip_rc(hipGetLastError());
 }
 

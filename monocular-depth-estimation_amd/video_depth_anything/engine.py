@@ -108,25 +108,31 @@ class Engine:
 
     def conv3(self, x, w, bias, cout, stride=1, relu_in=False, out=None, ldc=None, resized=None, **kw):
         """x: [frames, h, w, cin] -> [frames, oh, ow, cout] (3x3, padding 1), both of the head's storage type.
-        ``resized=(h', w')``: the convolution runs on the bilinear resampling of x to h' x w'; with 16-bit storage the
-        kernel resamples while it loads its input patches and the resized map is never materialised."""
-        if resized is not None and tuple(resized) != tuple(x.shape[1:3]):
-            if self.split or stride != 1:
+        ``resized=(h', w')``: the convolution runs on the bilinear resampling of x to h' x w'.  With 16-bit storage the
+        kernel resamples while it loads its input patches; with fp32 storage the resampling writes the operand pieces of the
+        convolution: either way the resized map is never materialised in the storage type."""
+        f, h, wd, cin = x.shape
+        pre = None
+        if resized is not None and tuple(resized) != (h, wd):
+            if self.split and self.fused_split and stride == 1 and not relu_in and cin % 64 == 0:
+                sh, sw, (h, wd) = h, wd, resized
+                pre = Pieces(_empty((f * h * wd, self.pw * cin), SPLIT_DTYPE, self.dev))
+                hip.bilinear_nhwc_pieces(x, pre.t, f, sh, sw, h, wd, cin, self.act_scale, self.layout, self.sat)
+            elif self.split or stride != 1:
                 x = self.resize(x, *resized)
-            else:
-                f, sh, sw, cin = x.shape
                 h, wd = resized
+            else:
+                sh, sw, (h, wd) = h, wd, resized
                 if out is None:
                     out = _empty((f, h, wd, cout), self.hdt, self.dev)
                 hip.gemm(x.reshape(f * sh * sw, cin), self.weight(w, kw), out, M=f * h * wd, N=cout, K=9 * cin, lda=0,
                          ldc=cout if ldc is None else ldc, bias=bias, relu_in=relu_in, conv=(h, wd, cin, h, wd, 1),
                          upsample_from=(sh, sw), **kw)
                 return out
-        f, h, wd, cin = x.shape
         oh, ow = (h - 1) // stride + 1, (wd - 1) // stride + 1
         if out is None:
             out = _empty((f, oh, ow, cout), self.hdt, self.dev)
-        a, relu_in = self.operand(x.reshape(f * h * wd, cin), relu_in)
+        a, relu_in = self.operand(pre if pre is not None else x.reshape(f * h * wd, cin), relu_in)
         cin = a.shape[1]
         hip.gemm(a, self.weight(w, kw), out, M=f * oh * ow, N=cout, K=9 * cin, lda=0, ldc=cout if ldc is None else ldc, bias=bias,
                  relu_in=relu_in, conv=(h, wd, cin, oh, ow, stride), **kw)

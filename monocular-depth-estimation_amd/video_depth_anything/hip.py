@@ -20,7 +20,7 @@ GROUPNORM_MAX_SPLITS = 64        # VDA_GROUPNORM_MAX_SPLITS: sizes the scratch o
 LSQ_SUMS_DOUBLES = 5 + 4 * 256   # VDA_LSQ_SUMS_DOUBLES: five totals + per-workgroup partials of scale_shift_sums()
 
 EXPORTS = [
-    "vda_version", "vda_gemm", "vda_gemm_kernel_choice", "vda_attention", "vda_attention_pairs", "vda_layernorm", "vda_round_rowstats", "vda_rowstats_finish", "vda_groupnorm", "vda_groupnorm_static", "vda_bilinear_nhwc", "vda_bilinear_f32",
+    "vda_version", "vda_gemm", "vda_gemm_kernel_choice", "vda_attention", "vda_attention_pairs", "vda_layernorm", "vda_round_rowstats", "vda_rowstats_finish", "vda_groupnorm", "vda_groupnorm_static", "vda_bilinear_nhwc", "vda_bilinear_nhwc_pieces", "vda_bilinear_f32",
     "vda_im2col_patch14", "vda_assemble_tokens", "vda_temporal_attention", "vda_scale_shift_sums", "vda_solve_scale_shift",
     "vda_affine_blend", "vda_preprocess_u8", "vda_split3", "vda_sample_points", "vda_scale_frames", "vda_minmax_f32", "vda_colorize_u8",
 ]
@@ -40,6 +40,14 @@ class GemmArgs(C.Structure):
         ("out16", C.c_void_p), ("row_part", C.c_void_p), ("ld16", C.c_int), ("row_stat", C.c_void_p), ("w_colsum", C.c_void_p),
         ("split_out", C.c_int), ("split_scale", C.c_float), ("sat_flag", C.c_void_p), ("ab_pairs", C.c_int),
     ]
+
+
+PIECES_TRIPLE, PIECES_PAIRS = 0, 1          # VDA_PIECES_*: layouts of an fp32 operand's 16-bit hi/lo pieces
+
+
+def pieces_width(layout, K):
+    """Stored columns of K operand columns."""
+    return 2 * K if layout == PIECES_PAIRS else 3 * K
 
 
 _lib = None
@@ -68,6 +76,7 @@ def lib():
                                            C.c_float, C.c_int, C.c_void_p]
         l.vda_bilinear_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
         l.vda_bilinear_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
+        l.vda_bilinear_nhwc_pieces.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]
         l.vda_im2col_patch14.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.vda_split3.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.c_int, C.c_void_p, C.c_void_p]
@@ -275,13 +284,6 @@ def attention(qkv, out, frames, n_tok, heads):
     _check(lib().vda_attention(_ptr(qkv), _ptr(out), frames, n_tok, heads, _type(qkv), _stream()), "vda_attention")
 
 
-PIECES_TRIPLE, PIECES_PAIRS = 0, 1          # VDA_PIECES_*
-
-
-def pieces_width(layout, K):
-    return 2 * K if layout == PIECES_PAIRS else 3 * K
-
-
 def attention_pairs(qkv2, out3, frames, n_tok, heads, scale, out_layout=PIECES_TRIPLE):
     """vda_attention_pairs: fp16 [hi | lo] planes of scale * qkv in, fp16 pieces of scale * output out (``out_layout``)."""
     _dev(qkv2, out3)
@@ -367,6 +369,17 @@ def bilinear_nhwc(x, out, frames, in_h, in_w, out_h, out_w, Cdim):
     _need("vda_bilinear_nhwc", x=(x, frames * in_h * in_w * Cdim), out=(out, frames * out_h * out_w * Cdim))
     _check(lib().vda_bilinear_nhwc(_ptr(x), _ptr(out), frames, in_h, in_w, out_h, out_w, Cdim, _type(x), _stream()),
            "vda_bilinear_nhwc")
+
+
+def bilinear_nhwc_pieces(x, out, frames, in_h, in_w, out_h, out_w, Cdim, scale, layout=PIECES_TRIPLE, sat_flag=None):
+    """fp32 NHWC map -> the 16-bit operand pieces of ``scale`` times its bilinear resampling (``out``'s type, ``layout``)."""
+    _dev(x, out, sat_flag)
+    if x.dtype != torch.float32 or (sat_flag is not None and sat_flag.dtype != torch.int32):
+        raise TypeError("vda_bilinear_nhwc_pieces: fp32 map, int32 flag")
+    _need("vda_bilinear_nhwc_pieces", x=(x, frames * in_h * in_w * Cdim), out=(out, frames * out_h * out_w * pieces_width(layout, Cdim)),
+          sat_flag=(sat_flag, 1))
+    _check(lib().vda_bilinear_nhwc_pieces(_ptr(x), _ptr(out), frames, in_h, in_w, out_h, out_w, Cdim, _type(out), float(scale),
+                                          int(layout), _ptr(sat_flag), _stream()), "vda_bilinear_nhwc_pieces")
 
 
 def bilinear_f32(x, out, frames, in_h, in_w, out_h, out_w, relu=False):

@@ -883,6 +883,26 @@ def test_attention_on_operand_pieces_with_scores_far_from_zero():
     close((out3[..., :D].float() + out3[..., D:2 * D].float()) / sc, want, 1e-5, "attention on pieces, sharp rows")
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("piece", HALVES)
+@pytest.mark.parametrize("ih,iw,oh,ow,C", [(19, 19, 37, 37, 256), (10, 14, 35, 49, 64), (6, 6, 6, 6, 128)])
+def test_bilinear_writes_operand_pieces(ih, iw, oh, ow, C, piece, layout):
+    """vda_bilinear_nhwc_pieces: the pieces vda_split3 makes of vda_bilinear_nhwc's fp32 result, bit for bit."""
+    frames, sc = 3, ACT_SCALE[piece]
+    x = rnd((frames, ih, iw, C), 1, 2.0, torch.float32)
+    y = torch.empty((frames, oh, ow, C), dtype=torch.float32, device=DEV)
+    hip.bilinear_nhwc(x, y, frames, ih, iw, oh, ow, C)
+    rows, width = frames * oh * ow, hip.pieces_width(layout, C)
+    want = torch.empty((rows, width), dtype=piece, device=DEV)
+    hip.split3(y.reshape(rows, C), want, rows, C, C, C, scale=sc, layout=layout)
+    got = torch.full((rows, width), float("nan"), dtype=piece, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.bilinear_nhwc_pieces(x, got, frames, ih, iw, oh, ow, C, sc, layout, flag)
+    assert torch.equal(got, want) and int(flag.item()) == 0
+    hip.bilinear_nhwc_pieces(x * 1e4, got, frames, ih, iw, oh, ow, C, sc, layout, flag)
+    assert int(flag.item()) == (1 if piece == torch.float16 else 0)
+
+
 def test_split3_reports_saturation():
     x = rnd((64, 128), 1, 1.0, torch.float32)
     out = torch.empty((64, 3 * 128), dtype=torch.float16, device=DEV)
