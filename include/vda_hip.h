@@ -318,6 +318,42 @@ int vda_scale_frames(const float* depth, const float* scales, float* out, int fr
 int vda_minmax_f32(const float* x, float* minmax, long n, void* stream);
 int vda_colorize_u8(const float* depth, const float* minmax, const uint8_t* lut, uint8_t* out, long n, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Colour-map variants of the reference's drivers, on device-resident fp32 maps.  A colour table is matplotlib's for the map:
+ * 259 RGB byte triples = the 256 entries times 255, truncated, followed by the under, over and bad (NaN) colours; an index
+ * is taken from a value v in [0, 1] as matplotlib does (v * 256 truncated, 256 -> 255, negative -> under, larger -> over).
+ * The arithmetic runs in float32, or in float64 where `f64` is set: whichever numpy evaluates the reference's expression in
+ * for the scalar types at hand (the caller knows them).
+ * vda_colormap_u8: out[i] = table[index((clip(x[i], clip_lo, clip_hi) - sub) / div)]; x[i] >= cap takes the last of the 256
+ *   colours.  Covers run1dist.py:46-65 (contrast stretching between two percentiles), :67-91 (distance capping) and :173-177.
+ * vda_colorize_zones_u8: run1.py:28-60: x <= critical_max -> lut_critical[index(x / critical_max)]; up to traffic_max ->
+ *   lut_traffic[index((x - critical_max) / traffic_range)]; beyond -> (64, 64, 64); NaN -> (0, 0, 0).
+ * vda_range_focus_f32: run4.py:29-42: out = x * (x > far ? far_weight : 1), then, with `stretch`,
+ *   clip((out - sub) / div, clip_lo, clip_hi) (the percentiles sub / div come from the caller).
+ * vda_quantize_u8 / vda_histogram_u8 / vda_colormap_bytes_u8: run1dist.py:27-44: g = (uint8)((x - lo) / range * 255); the
+ *   256-bin histogram of g (`hist` is added to: clear it first); out = table[index(remap[g] / 255)] for the equalisation table
+ *   `remap` the caller derives from the histogram (cv2.equalizeHist's rule; OpenCV is not available to pin it).
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_colormap_u8(const float* x, const uint8_t* lut, uint8_t* out, long n, double sub, double div, double clip_lo,
+                    double clip_hi, float cap, int f64, void* stream);
+int vda_colorize_zones_u8(const float* x, const uint8_t* lut_critical, const uint8_t* lut_traffic, uint8_t* out, long n,
+                          float critical_max, float traffic_max, float traffic_range, void* stream);
+int vda_range_focus_f32(const float* x, float* out, long n, float far, float far_weight, int stretch, double sub, double div,
+                        double clip_lo, double clip_hi, int f64, void* stream);
+int vda_quantize_u8(const float* x, uint8_t* out, long n, float lo, float range, void* stream);
+int vda_histogram_u8(const uint8_t* x, uint32_t* hist, long n, void* stream);
+int vda_colormap_bytes_u8(const uint8_t* g, const uint8_t* remap, const uint8_t* lut, uint8_t* out, long n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Temporal refinement step of the metric driver (metric_depth/run2.py:28-40, 76): out = w_cur * cur + w_prev * warp(prev),
+ * where warp samples `prev` at (x + flow[y][x][0], y + flow[y][x][1]) the way cv2.remap(INTER_LINEAR, BORDER_REFLECT) does
+ * (position rounded to 1/32 pixel, four taps, mirrored border).  fp32 maps [h][w], flow [h][w][2] (the caller's optical
+ * flow: the reference's Farneback estimator is an OpenCV routine and is not part of this library).  out must not alias prev.
+ * OpenCV is not available here, so parity of the sampling with cv2.remap is unpinned; the blend is exact.
+ * ------------------------------------------------------------------------------------------------------------- */
+int vda_warp_blend_f32(const float* prev, const float* cur, const float* flow, float* out, int h, int w, float w_cur, float w_prev,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

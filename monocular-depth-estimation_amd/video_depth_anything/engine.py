@@ -151,7 +151,9 @@ class Engine:
         """The four tapped, normalised token maps [frames * hw, D].  The encoder treats every frame on its own, so the frames
         are split into ``self.encoder_streams`` groups that run on separate HIP streams: while one group's workgroups drain
         at the end of a kernel (a GEMM grid rarely fills its last round of tiles) or wait on HBM (LayerNorm, residual
-        epilogues), the other group's matrix-bound kernels take the idle CUs.  Same kernels on the same rows: same bits.
+        epilogues), the other group's matrix-bound kernels take the idle CUs.  Same kernels on the same rows: same bits (in
+        the head the number of frames per launch can change which convolution kernel runs, and with it the order of a sum:
+        one stream against two agree to rounding there, see head()).
 
         ``carried = (previous taps, slots)``: the first ``len(slots)`` frames are the frames at ``slots`` of an earlier call
         whose tap buffers are given; their rows are copied instead of computed (a frame's encoder output does not depend on

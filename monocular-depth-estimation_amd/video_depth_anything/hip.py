@@ -23,6 +23,8 @@ EXPORTS = [
     "vda_version", "vda_gemm", "vda_gemm_kernel_choice", "vda_attention", "vda_attention_pairs", "vda_layernorm", "vda_round_rowstats", "vda_rowstats_finish", "vda_groupnorm", "vda_groupnorm_static", "vda_bilinear_nhwc", "vda_bilinear_nhwc_pieces", "vda_bilinear_f32",
     "vda_im2col_patch14", "vda_assemble_tokens", "vda_temporal_attention", "vda_scale_shift_sums", "vda_solve_scale_shift",
     "vda_affine_blend", "vda_preprocess_u8", "vda_split3", "vda_sample_points", "vda_scale_frames", "vda_minmax_f32", "vda_colorize_u8",
+    "vda_colormap_u8", "vda_colorize_zones_u8", "vda_range_focus_f32", "vda_quantize_u8", "vda_histogram_u8", "vda_colormap_bytes_u8",
+    "vda_warp_blend_f32",
 ]
 
 
@@ -92,6 +94,13 @@ def lib():
         l.vda_scale_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p]
         l.vda_minmax_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         l.vda_colorize_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+        l.vda_colormap_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long] + [C.c_double] * 4 + [C.c_float, C.c_int, C.c_void_p]
+        l.vda_colorize_zones_u8.argtypes = [C.c_void_p] * 4 + [C.c_long, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        l.vda_range_focus_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_float, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_void_p]
+        l.vda_quantize_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_float, C.c_void_p]
+        l.vda_histogram_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+        l.vda_colormap_bytes_u8.argtypes = [C.c_void_p] * 4 + [C.c_long, C.c_void_p]
+        l.vda_warp_blend_f32.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
         for name in EXPORTS[1:]:
             getattr(l, name).restype = C.c_int
         _lib = l
@@ -463,3 +472,67 @@ def colorize_u8(depth, minmax, lut, out, n):
     _dev(depth, minmax, lut, out)
     _need("vda_colorize_u8", depth=(depth, n), minmax=(minmax, 2), lut=(lut, 3 * 256), out=(out, n if lut is None else 3 * n))
     _check(lib().vda_colorize_u8(_ptr(depth), _ptr(minmax), _ptr(lut), _ptr(out), n, _stream()), "vda_colorize_u8")
+
+
+CMAP_ROWS = 259        # a colour table: matplotlib's 256 entries, then the under, over and bad colours
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("fp32 maps")
+
+
+def colormap_u8(x, lut, out, n, sub, div, clip_lo=-float("inf"), clip_hi=float("inf"), cap=float("inf"), f64=False):
+    _dev(x, lut, out)
+    _f32(x)
+    _need("vda_colormap_u8", x=(x, n), lut=(lut, 3 * CMAP_ROWS), out=(out, 3 * n))
+    _check(lib().vda_colormap_u8(_ptr(x), _ptr(lut), _ptr(out), n, float(sub), float(div), float(clip_lo), float(clip_hi), float(cap),
+                                 int(bool(f64)), _stream()), "vda_colormap_u8")
+
+
+def colorize_zones_u8(x, lut_critical, lut_traffic, out, n, critical_max, traffic_max, traffic_range):
+    _dev(x, lut_critical, lut_traffic, out)
+    _f32(x)
+    _need("vda_colorize_zones_u8", x=(x, n), lut_critical=(lut_critical, 3 * CMAP_ROWS), lut_traffic=(lut_traffic, 3 * CMAP_ROWS), out=(out, 3 * n))
+    _check(lib().vda_colorize_zones_u8(_ptr(x), _ptr(lut_critical), _ptr(lut_traffic), _ptr(out), n, float(critical_max),
+                                       float(traffic_max), float(traffic_range), _stream()), "vda_colorize_zones_u8")
+
+
+def range_focus_f32(x, out, n, far=float("inf"), far_weight=1.0, stretch=False, sub=0.0, div=1.0, clip_lo=0.0, clip_hi=1.0, f64=False):
+    _dev(x, out)
+    _f32(x, out)
+    _need("vda_range_focus_f32", x=(x, n), out=(out, n))
+    _check(lib().vda_range_focus_f32(_ptr(x), _ptr(out), n, float(far), float(far_weight), int(bool(stretch)), float(sub), float(div),
+                                     float(clip_lo), float(clip_hi), int(bool(f64)), _stream()), "vda_range_focus_f32")
+
+
+def quantize_u8(x, out, n, lo, rng):
+    _dev(x, out)
+    _f32(x)
+    _need("vda_quantize_u8", x=(x, n), out=(out, n))
+    _check(lib().vda_quantize_u8(_ptr(x), _ptr(out), n, float(lo), float(rng), _stream()), "vda_quantize_u8")
+
+
+def histogram_u8(x, hist, n):
+    _dev(x, hist)
+    if x.dtype != torch.uint8 or hist.dtype != torch.int32:
+        raise TypeError("vda_histogram_u8: bytes in, 256 int32 bins")
+    _need("vda_histogram_u8", x=(x, n), hist=(hist, 256))
+    _check(lib().vda_histogram_u8(_ptr(x), _ptr(hist), n, _stream()), "vda_histogram_u8")
+
+
+def colormap_bytes_u8(g, remap, lut, out, n):
+    _dev(g, remap, lut, out)
+    _need("vda_colormap_bytes_u8", g=(g, n), remap=(remap, 256), lut=(lut, 3 * CMAP_ROWS), out=(out, 3 * n))
+    _check(lib().vda_colormap_bytes_u8(_ptr(g), _ptr(remap), _ptr(lut), _ptr(out), n, _stream()), "vda_colormap_bytes_u8")
+
+
+def warp_blend_f32(prev, cur, flow, out, h, w, w_cur, w_prev):
+    _dev(prev, cur, flow, out)
+    _f32(prev, cur, flow, out)
+    if out.data_ptr() == prev.data_ptr():
+        raise ValueError("vda_warp_blend_f32: out must not alias prev")
+    _need("vda_warp_blend_f32", prev=(prev, h * w), cur=(cur, h * w), flow=(flow, 2 * h * w), out=(out, h * w))
+    _check(lib().vda_warp_blend_f32(_ptr(prev), _ptr(cur), _ptr(flow), _ptr(out), h, w, float(w_cur), float(w_prev), _stream()),
+           "vda_warp_blend_f32")

@@ -7,8 +7,10 @@ extrapolation over the frame index of the factors that exist (a single factor ap
 multiplied by its factor.  The per-frame samples and the multiply run as two launches over device-resident maps
 (``infer_video_depth_device``); the N scalars in between are host arithmetic in float64, as in the reference.
 
-The optional optical-flow refinement of the reference (Farneback flow + remap + 0.7 / 0.3 blend, run2.py:22-40, 68-77) is
-not built: OpenCV is not available to pin its arithmetic.
+The optional temporal refinement of the reference (run2.py:22-40, 68-77) is Farneback optical flow, a remap of the previous
+refined map along the flow and a 0.7 / 0.3 blend.  ``temporal_refine`` does the remap and the blend on the device from flow
+fields the caller supplies; the flow estimator itself is an OpenCV routine and is not part of this library, and with OpenCV
+unavailable the remap's parity with ``cv2.remap`` is unpinned (the blend is exact).
 """
 import numpy as np
 import torch
@@ -86,3 +88,34 @@ def _scale_factors(pred, refs):
             # python float / numpy float32 scalar: the reference's division runs in float32 (numpy >= 2 promotion rules)
             s[i] = float(np.float32(r[2]) / np.float32(pred[i]))
     return propagate_scale_factors(s)
+
+
+def temporal_refine(scaled_depths, flows, prev_depth=None, w_cur=0.7, w_prev=0.3):
+    """The refinement chain of run2.py:68-77 on device-resident maps: ``refined[0] = scaled[0]`` and
+    ``refined[i] = w_cur * scaled[i] + w_prev * warp(refined[i - 1], flows[i - 1])``, where ``flows[i - 1]`` (fp32 ``[H, W, 2]``)
+    is the optical flow from frame i - 1 to frame i and ``warp`` samples like ``cv2.remap(INTER_LINEAR, BORDER_REFLECT)``.
+    With ``prev_depth`` (the last refined map of the previous chunk) frame 1 blends with it unwarped, as the reference does.
+    ``scaled_depths``: fp32 ``[N, H, W]`` device tensor or numpy array; ``flows``: ``[N - 1, H, W, 2]`` likewise (``flows[0]`` is
+    not read when ``prev_depth`` is given).  Returns the refined maps in the type of ``scaled_depths``."""
+    host = isinstance(scaled_depths, np.ndarray)
+    dev = torch.device(f"cuda:{torch.cuda.current_device()}") if host else scaled_depths.device
+
+    def on_dev(t):
+        return torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).to(dev) if isinstance(t, np.ndarray) else t.float().contiguous()
+
+    with torch.cuda.device(dev):
+        scaled = on_dev(scaled_depths)
+        n, h, w = scaled.shape
+        refined = torch.empty_like(scaled)
+        refined[0] = scaled[0]
+        zero_flow = None
+        for i in range(1, n):
+            if i == 1 and prev_depth is not None:
+                prev = on_dev(prev_depth)
+                if zero_flow is None:
+                    zero_flow = torch.zeros((h, w, 2), dtype=torch.float32, device=dev)
+                flow = zero_flow                          # the reference blends the previous chunk's map as it is
+            else:
+                prev, flow = refined[i - 1], on_dev(flows[i - 1])
+            hip.warp_blend_f32(prev, scaled[i], flow, refined[i], h, w, w_cur, w_prev)
+        return refined.cpu().numpy() if host else refined

@@ -9,7 +9,7 @@ Weights come from the build's seeded generator (spec.synth_state_dict) and are l
 ``load_state_dict(strict=True)``; only inputs' seeds and the reference's outputs are stored.  While generating,
 the oracle restatement is checked against every reference output (fp32 vs fp32).
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py [--only-clamped | --only-outliers | --only-lidar | --only-visualisation]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py [--only-clamped | --only-outliers | --only-lidar | --only-visualisation | --only-colour-variants]
 """
 import json
 import os
@@ -207,6 +207,67 @@ def visualisation_goldens():
     np.savez_compressed(os.path.join(GOLD, "g9_visualisation.npz"), **g9)
 
 
+COLORMAPS = ("turbo", "viridis", "plasma", "inferno", "magma", "Reds", "jet", "gray")
+
+
+def colour_variant_cases():
+    """Seeded metric-like depth maps for the colour-variant goldens (G10): 0 .. 80 m with a far tail, NaNs, negatives and
+    values exactly on the zone boundaries."""
+    rs = np.random.RandomState(101)
+    a = (rs.rand(36, 60).astype(np.float32) ** 2) * 80
+    a[3, 4], a[3, 5], a[3, 6], a[3, 7] = 10.0, 30.0, 0.0, 50.0
+    a[5, 9] = np.nan
+    a[6, 2] = -1.5
+    b = (rs.rand(36, 60).astype(np.float32) * 12 + 0.5)
+    return {"wide": a, "near": b}
+
+
+def colour_variant_goldens():
+    """G10: the colour variants of run1.py:28-60, run1dist.py:46-91,173-177 and run4.py:29-42, from the reference's own functions
+    (its scripts imported with the usual stand-ins); also writes the package's colour tables from matplotlib."""
+    import importlib
+    import matplotlib.pyplot as plt
+    imageio = types.ModuleType("imageio")
+    sys.modules.setdefault("imageio", imageio)
+    sys.path.insert(0, "/root/reference")
+    run1, run1dist, run4 = (importlib.import_module(n) for n in ("run1", "run1dist", "run4"))
+    tables = {}
+    for name in COLORMAPS:
+        cm_ = plt.get_cmap(name)
+        cm_(0.5)                                        # builds the table
+        tables[name] = (cm_._lut[:, :3] * 255).astype(np.uint8)
+        assert tables[name].shape == (259, 3)
+    np.savez_compressed(os.path.join(ROOT, "monocular-depth-estimation_amd", "video_depth_anything", "colormaps_u8.npz"), **tables)
+    g = {}
+    for name, d in colour_variant_cases().items():
+        g[name] = d
+        ref = run1.apply_traffic_zones(d, 10.0, 30.0)
+        assert np.array_equal(O.apply_traffic_zones(d, tables["Reds"], tables["viridis"], 10.0, 30.0), ref)
+        g[name + "_zones"] = ref
+        ref = run1.apply_traffic_zones(d)                       # the integer defaults
+        assert np.array_equal(O.apply_traffic_zones(d, tables["Reds"], tables["viridis"]), ref)
+        g[name + "_zones_default"] = ref
+        vmin, vmax = np.nanmin(d), np.nanmax(d)
+        for cmap in ("turbo", "plasma"):
+            ref = run1dist.apply_contrast_stretching(d, colormap=cmap)
+            assert np.array_equal(O.apply_contrast_stretching(d, tables[cmap]), ref)
+            g[f"{name}_stretch_{cmap}"] = ref
+            ref = run1dist.apply_distance_capping(d, vmin, vmax, 25.0, cmap)
+            assert np.array_equal(O.apply_distance_capping(d, vmin, vmax, 25.0, tables[cmap]), ref)
+            g[f"{name}_cap_{cmap}"] = ref
+            ref = (plt.get_cmap(cmap)((d - vmin) / (vmax - vmin + 1e-8))[:, :, :3] * 255).astype(np.uint8)      # run1dist.py:175-177
+            assert np.array_equal(O.apply_colormap(d, vmin, vmax, tables[cmap]), ref)
+            g[f"{name}_plain_{cmap}"] = ref
+        clean = np.nan_to_num(d, nan=3.0)                      # run4 takes percentiles of comparisons: keep NaN out
+        ref = clean * run4.create_range_mask(clean, 0.0, 50.0)
+        ref = run4.enhance_range(ref, 0.0, 50.0).astype(np.float32)
+        mine = O.focus_range(clean, 0.0, 50.0)
+        assert np.array_equal(mine, ref), np.abs(mine - ref).max()
+        g[name + "_focus"] = ref
+    np.savez_compressed(os.path.join(GOLD, "g10_colour_variants.npz"), **g)
+    print("G10 written:", len(g), "arrays")
+
+
 def main():
     os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
     sys.dont_write_bytecode = True
@@ -224,6 +285,9 @@ def main():
         return
     if "--only-visualisation" in sys.argv:
         visualisation_goldens()
+        return
+    if "--only-colour-variants" in sys.argv:
+        colour_variant_goldens()
         return
     from video_depth_anything.util.transform import Resize
     from video_depth_anything.dinov2_layers.block import Block as RefBlock
@@ -382,6 +446,7 @@ def main():
     outlier_profile_goldens(RefVDA)
     lidar_goldens()
     visualisation_goldens()
+    colour_variant_goldens()
     print("goldens written to", GOLD)
     for f in sorted(os.listdir(GOLD)):
         print(f"  {f:28s} {os.path.getsize(os.path.join(GOLD, f)) / 1024:.0f} KiB")

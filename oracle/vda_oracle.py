@@ -452,6 +452,129 @@ def colorize_depth(frames, table_u8=None):
 # ----------------------------------------------------------------------------------------------------------
 # error metrics
 # ----------------------------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------------------
+# colour variants of the reference's drivers and the metric driver's temporal refinement (numpy restatements)
+# ----------------------------------------------------------------------------------------------------------
+def cmap_lookup(x01, table_u8):
+    """matplotlib's ``Colormap.__call__`` on floats in [0, 1] followed by ``(rgb * 255).astype(uint8)``, with the table already in
+    bytes: ``table_u8`` [259, 3] = the 256 entries, then the under / over / bad colours.  Index = x * 256 in the array's own
+    precision, truncated; exactly 256 -> 255; negative -> under; >= 256 -> over; NaN -> bad."""
+    xa = np.array(x01, copy=True)
+    xa *= 256
+    xa[xa == 256] = 255
+    under, over, bad = xa < 0, xa >= 256, np.isnan(xa)
+    with np.errstate(invalid="ignore"):
+        idx = xa.astype(int)
+    idx[under], idx[over], idx[bad] = 256, 257, 258
+    return table_u8[idx]
+
+
+def apply_traffic_zones(depth, reds_u8, viridis_u8, critical_max=10, traffic_max=30):
+    """Reference: run1.py:28-60."""
+    out = np.zeros(depth.shape + (3,), np.uint8)
+    m = depth <= critical_max
+    out[m] = cmap_lookup(depth[m] / critical_max, reds_u8)
+    m = (depth > critical_max) & (depth <= traffic_max)
+    out[m] = cmap_lookup((depth[m] - critical_max) / (traffic_max - critical_max), viridis_u8)
+    out[depth > traffic_max] = [64, 64, 64]
+    return out
+
+
+def apply_colormap(depth, vmin, vmax, table_u8):
+    """Reference: run1dist.py:173-177."""
+    return cmap_lookup((depth - vmin) / (vmax - vmin + 1e-8), table_u8)
+
+
+def apply_contrast_stretching(depth, table_u8, percentile_low=2, percentile_high=98):
+    """Reference: run1dist.py:46-65."""
+    flat = depth.flatten()
+    flat = flat[~np.isnan(flat)]
+    lo, hi = np.percentile(flat, percentile_low), np.percentile(flat, percentile_high)
+    return cmap_lookup((np.clip(depth, lo, hi) - lo) / (hi - lo), table_u8)
+
+
+def apply_distance_capping(depth, vmin, vmax, cap, table_u8):
+    """Reference: run1dist.py:67-91."""
+    out = cmap_lookup((np.clip(depth, vmin, cap) - vmin) / (cap - vmin + 1e-8), table_u8)
+    out[depth >= cap] = table_u8[255]
+    return out
+
+
+def focus_range(depth, min_range=0.0, max_range=50.0):
+    """Reference: run4.py:29-42 as applied at run4.py:105-111 (mask, then contrast stretch of the product, stored as float32)."""
+    mask = np.ones_like(depth)
+    mask[depth > max_range] = 0.1
+    d = depth * mask
+    in_range = (d >= min_range) & (d <= max_range)
+    if np.any(in_range):
+        p2, p98 = np.percentile(d[in_range], [2, 98])
+        d = np.clip((d - p2) / (p98 - p2 + 1e-8), 0, 1)
+    return d.astype(np.float32)
+
+
+def equalize_hist(g):
+    """cv2.equalizeHist on a uint8 image, restated from OpenCV's documented algorithm (parity unpinned: OpenCV is not
+    importable): lut[first occupied bin] = 0, lut[i] = round_half_even(255 / (total - h[first]) * cumulative count after it)."""
+    hist = np.bincount(g.reshape(-1), minlength=256)
+    total, first = int(hist.sum()), int(np.argmax(hist > 0))
+    lut = np.zeros(256, np.uint8)
+    if hist[first] == total:
+        lut[:] = first
+    else:
+        scale = np.float32(255.0) / np.float32(total - hist[first])
+        acc = 0
+        for i in range(first + 1, 256):
+            acc += int(hist[i])
+            lut[i] = min(max(int(np.rint(np.float32(acc) * scale)), 0), 255)
+    return lut[g]
+
+
+def apply_histogram_equalization(depth, vmin, vmax, table_u8):
+    """Reference: run1dist.py:27-44 (with ``equalize_hist`` standing in for cv2.equalizeHist)."""
+    g = ((depth - vmin) / (vmax - vmin) * 255).astype(np.uint8)
+    return cmap_lookup(equalize_hist(g).astype(np.float32) / 255.0, table_u8)
+
+
+def warp_depth(prev_depth, flow):
+    """Reference: metric_depth/run2.py:28-40 with cv2.remap(INTER_LINEAR, BORDER_REFLECT) restated from OpenCV's documented
+    behaviour (parity unpinned): positions rounded to 1/32 pixel, four taps with float32 weights, border mirrored about the edge."""
+    h, w = flow.shape[:2]
+    fm = np.stack(np.meshgrid(np.arange(w), np.arange(h)), axis=-1) + flow
+    mx, my = fm[..., 0].astype(np.float32), fm[..., 1].astype(np.float32)
+    sx, sy = np.rint(mx * np.float32(32)).astype(np.int64), np.rint(my * np.float32(32)).astype(np.int64)
+    ix, iy = sx >> 5, sy >> 5
+    fx, fy = (sx & 31).astype(np.float32) / np.float32(32), (sy & 31).astype(np.float32) / np.float32(32)
+
+    def reflect(p, n):
+        p = np.array(p, copy=True)
+        if n == 1:
+            return np.zeros_like(p)
+        for _ in range(64):
+            bad = (p < 0) | (p >= n)
+            if not bad.any():
+                break
+            p = np.where(p < 0, -p - 1, np.where(p >= n, 2 * n - p - 1, p))
+        return p
+
+    x0, x1, y0, y1 = reflect(ix, w), reflect(ix + 1, w), reflect(iy, h), reflect(iy + 1, h)
+    one = np.float32(1)
+    src = prev_depth.astype(np.float32)
+    acc = src[y0, x0] * ((one - fy) * (one - fx))
+    acc = acc + src[y0, x1] * ((one - fy) * fx)
+    acc = acc + src[y1, x0] * (fy * (one - fx))
+    acc = acc + src[y1, x1] * (fy * fx)
+    return acc.astype(np.float32)
+
+
+def temporal_refine(scaled_depths, flows, prev_depth=None):
+    """Reference: metric_depth/run2.py:68-77 with the optical flow given instead of computed."""
+    refined = [scaled_depths[0]]
+    for i in range(1, len(scaled_depths)):
+        warped = prev_depth if (i == 1 and prev_depth is not None) else warp_depth(refined[-1], flows[i - 1])
+        refined.append(0.7 * scaled_depths[i] + 0.3 * warped)
+    return refined
+
+
 def max_rel_err(a, b):
     """max |a-b| / max(|b|, 1e-3 max|b|): relative error with a floor, because the depth is ReLU-clamped."""
     a = np.asarray(a, dtype=np.float64)

@@ -182,3 +182,52 @@ def test_depth_visualisation_oracle_matches_reference_frames(golden_dir):
     table = np.load(os.path.join(os.path.dirname(spec.__file__), "inferno_u8.npy"))
     assert np.array_equal(O.colorize_depth(g["depths"], table), g["inferno"])
     assert np.array_equal(O.colorize_depth(g["depths"], None), g["gray"])
+
+
+def colour_tables():
+    return np.load(os.path.join(os.path.dirname(spec.__file__), "colormaps_u8.npz"))
+
+
+def test_colour_variant_oracle_matches_reference_frames(golden_dir):
+    """The restatements of run1.py:28-60, run1dist.py:46-91,173-177 and run4.py:29-42 against the bytes / maps the
+    reference's own functions returned (G10), through the shipped colour tables."""
+    g = np.load(os.path.join(golden_dir, "g10_colour_variants.npz"))
+    t = colour_tables()
+    assert all(t[k].shape == (259, 3) and t[k].dtype == np.uint8 for k in t.files)
+    for name in ("wide", "near"):
+        d = g[name]
+        assert np.array_equal(O.apply_traffic_zones(d, t["Reds"], t["viridis"], 10.0, 30.0), g[name + "_zones"])
+        assert np.array_equal(O.apply_traffic_zones(d, t["Reds"], t["viridis"]), g[name + "_zones_default"])
+        vmin, vmax = np.nanmin(d), np.nanmax(d)
+        for cmap in ("turbo", "plasma"):
+            assert np.array_equal(O.apply_contrast_stretching(d, t[cmap]), g[f"{name}_stretch_{cmap}"])
+            assert np.array_equal(O.apply_distance_capping(d, vmin, vmax, 25.0, t[cmap]), g[f"{name}_cap_{cmap}"])
+            assert np.array_equal(O.apply_colormap(d, vmin, vmax, t[cmap]), g[f"{name}_plain_{cmap}"])
+        assert np.array_equal(O.focus_range(np.nan_to_num(d, nan=3.0), 0.0, 50.0), g[name + "_focus"])
+    assert (g["wide_zones"][3, 4] != 0).any() and tuple(g["wide_zones"][5, 9]) == (0, 0, 0)      # boundary pixel coloured, NaN black
+
+
+def test_equalisation_and_warp_restatements_have_the_documented_properties():
+    """cv2.equalizeHist and cv2.remap cannot be imported here: their restatements are checked against what the algorithms
+    guarantee (parity with OpenCV itself is unpinned)."""
+    rs = np.random.RandomState(5)
+    g = (rs.rand(40, 50) ** 3 * 200).astype(np.uint8)
+    e = O.equalize_hist(g)
+    assert e.min() == 0 and e.max() == 255
+    order = np.argsort(g.reshape(-1), kind="stable")
+    assert (np.diff(e.reshape(-1)[order].astype(int)) >= 0).all()              # monotone in the input value
+    assert np.array_equal(O.equalize_hist(np.full((4, 4), 7, np.uint8)), np.full((4, 4), 7, np.uint8))
+    prev = rs.rand(12, 17).astype(np.float32) * 30
+    zero = np.zeros((12, 17, 2), np.float32)
+    assert np.array_equal(O.warp_depth(prev, zero), prev)
+    shift = zero.copy()
+    shift[..., 0] = 1.0                                                        # sample one pixel to the right
+    w = O.warp_depth(prev, shift)
+    assert np.array_equal(w[:, :-1], prev[:, 1:]) and np.array_equal(w[:, -1], prev[:, -1])      # mirrored border repeats the edge
+    half = zero.copy()
+    half[..., 1] = 0.5
+    w = O.warp_depth(prev, half)
+    assert np.allclose(w[:-1], 0.5 * (prev[:-1] + prev[1:]), rtol=1e-6)
+    scaled = [prev, prev * 1.1, prev * 0.9]
+    ref = O.temporal_refine(scaled, [zero, zero])
+    assert np.allclose(ref[2], 0.7 * scaled[2] + 0.3 * (0.7 * scaled[1] + 0.3 * scaled[0]), rtol=1e-6)
