@@ -408,9 +408,13 @@ __device__ __forceinline__ void remainder_to_hi(unsigned& d, float a, unsigned h
 }
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256, 2) void attn_pairs_kernel(const f16* __restrict__ qkv, f16* __restrict__ out, int n_tok, int heads,
+__global__ __launch_bounds__(256, 3) void attn_pairs_kernel(const f16* __restrict__ qkv, f16* __restrict__ out, int n_tok, int heads,
                                                             int q_blocks, float s2, int out_form) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 32768];      // per buffer: K hi, K lo, V hi, V lo (8 KiB each)
+    // Tiles of 32 keys: per buffer K hi, K lo, V hi, V lo of 4 KiB each.  With 32 KiB per workgroup three workgroups share a CU
+    // (the registers allow three waves per SIMD): a wave's score products, exponentials and output products depend on each
+    // other in turn, so it is the other waves of the SIMD that keep the matrix pipe busy meanwhile.
+    constexpr int TK = 32, PLANE = TK * 128, BUF = 4 * PLANE;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int nwg = gridDim.x, xcd = blockIdx.x & 7;
@@ -434,21 +438,18 @@ __global__ __launch_bounds__(256, 2) void attn_pairs_kernel(const f16* __restric
         }
     }
 
+    // staging: one 16-byte piece of each plane per thread and tile
     const int srow = tid >> 3, sc = tid & 7;
     const f16* kbase = base + D;
     const f16* vbase = base + 2 * D;
+    const int kc = (sc ^ ((srow >> 1) & 7)) << 3, vc = (sc ^ (((srow >> 1) & 1) << 2)) << 3;
     auto stage_tile = [&](int kt, int buf) {
-        char* b0 = smem + buf * 32768;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = i * 32 + srow;
-            const size_t g = (size_t)min(kt * 64 + row, n_tok - 1) * ld;
-            const int kc = (sc ^ ((row >> 1) & 7)) << 3, vc = (sc ^ (((row >> 1) & 1) << 2)) << 3;
-            glds16(kbase + g + kc, b0 + i * 4096 + wave * 1024);
-            glds16(kbase + g + lo_off + kc, b0 + 8192 + i * 4096 + wave * 1024);
-            glds16(vbase + g + vc, b0 + 16384 + i * 4096 + wave * 1024);
-            glds16(vbase + g + lo_off + vc, b0 + 24576 + i * 4096 + wave * 1024);
-        }
+        char* b0 = smem + buf * BUF + wave * 1024;
+        const size_t g = (size_t)min(kt * TK + srow, n_tok - 1) * ld;
+        glds16(kbase + g + kc, b0);
+        glds16(kbase + g + lo_off + kc, b0 + PLANE);
+        glds16(vbase + g + vc, b0 + 2 * PLANE);
+        glds16(vbase + g + lo_off + vc, b0 + 3 * PLANE);
     };
 
     f32x16 o[2], negm;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void attn_pairs_kernel(const f16* __restric
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; negm[i] = 0.f; }
     float m_run = 0.f, l_run = 0.f;          // the running maximum in score units times scale^2; the sum of P_SCALE * p
 
-    const int nkt = (n_tok + 63) / 64;
+    const int nkt = (n_tok + TK - 1) / TK;
     stage_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -470,38 +471,31 @@ __global__ __launch_bounds__(256, 2) void attn_pairs_kernel(const f16* __restric
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) stage_tile(kt + 1, cur ^ 1);
-        const char* kh = smem + cur * 32768;
-        const char* kl = kh + 8192;
-        const char* vh = kh + 16384;
-        const char* vl = kh + 24576;
+        const char* kh = smem + cur * BUF;
+        const char* kl = kh + PLANE;
+        const char* vh = kh + 2 * PLANE;
+        const char* vl = kh + 3 * PLANE;
 
-        f32x16 s[2];
+        f32x16 sc_ = negm;
 #pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk) {
+        for (int ks = 0; ks < 4; ++ks) {
+            const int off = tile_off(r, 2 * ks + h);
+            const f16x8 khi = *reinterpret_cast<const f16x8*>(kh + off);
+            const f16x8 klo = *reinterpret_cast<const f16x8*>(kl + off);
+            sc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qhi[ks], sc_, 0, 0, 0);
+            sc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qlo[ks], sc_, 0, 0, 0);
+            sc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qhi[ks], sc_, 0, 0, 0);
+        }
+        if (kt == nkt - 1) {               // keys past the end of the sequence
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int off = tile_off(32 * kbk + r, 2 * ks + h);
-                const f16x8 khi = *reinterpret_cast<const f16x8*>(kh + off);
-                const f16x8 klo = *reinterpret_cast<const f16x8*>(kl + off);
-                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qhi[ks], ks == 0 ? negm : s[kbk], 0, 0, 0);
-                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qlo[ks], s[kbk], 0, 0, 0);
-                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qhi[ks], s[kbk], 0, 0, 0);
+            for (int i = 0; i < 16; ++i) {
+                const int key = kt * TK + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (key >= n_tok) sc_[i] = -INFINITY;
             }
         }
-        if (kt == nkt - 1) {
+        float mx = sc_[0];
 #pragma unroll
-            for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = kt * 64 + 32 * kbk + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key >= n_tok) s[kbk][i] = -INFINITY;
-                }
-        }
-        float mx = s[0][0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sc_[i]);
         if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > defer) != 0) {
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
@@ -511,48 +505,44 @@ __global__ __launch_bounds__(256, 2) void attn_pairs_kernel(const f16* __restric
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 o[0][i] *= alpha; o[1][i] *= alpha;
-                s[0][i] -= delta; s[1][i] -= delta;
+                sc_[i] -= delta;
                 negm[i] = -m_run;
             }
         }
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
-        u32x4 ph[2][2], pl[2][2];              // eight halves each: the B operands of the second product
+        u32x4 ph[2], pl[2];                    // eight halves each: the B operands of the second product
 #pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kbk][i], inv_s2, LOG2_P_SCALE));     // P_SCALE * p <= 2^14
-                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kbk][i + 1], inv_s2, LOG2_P_SCALE));
-                ps[i & 3] += p0;
-                ps[(i + 1) & 3] += p1;
-                const f16x2 hi = {(f16)p0, (f16)p1};                     // one packed conversion
-                const unsigned h = __builtin_bit_cast(unsigned, hi);
-                unsigned l = remainder_to_lo(p0, h);
-                remainder_to_hi(l, p1, h);
-                ph[kbk][i >> 3][(i & 7) >> 1] = h;
-                pl[kbk][i >> 3][(i & 7) >> 1] = l;
-            }
+        for (int i = 0; i < 16; i += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc_[i], inv_s2, LOG2_P_SCALE));     // P_SCALE * p <= 2^14
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc_[i + 1], inv_s2, LOG2_P_SCALE));
+            ps[i & 3] += p0;
+            ps[(i + 1) & 3] += p1;
+            const f16x2 hi = {(f16)p0, (f16)p1};                     // one packed conversion
+            const unsigned hh = __builtin_bit_cast(unsigned, hi);
+            unsigned ll = remainder_to_lo(p0, hh);
+            remainder_to_hi(ll, p1, hh);
+            ph[i >> 3][(i & 7) >> 1] = hh;
+            pl[i >> 3][(i & 7) >> 1] = ll;
+        }
         l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-                for (int s2i = 0; s2i < 2; ++s2i) {
-                    const int k0 = 32 * kbk + 16 * s2i + 4 * h + tq;
-                    const int o0 = v_off(k0, 32 * db + tcol), o1 = v_off(k0 + 8, 32 * db + tcol);
-                    const f16x4 a0 = read_tr_f16(vh + o0);
-                    const f16x4 a1 = read_tr_f16(vh + o1);
-                    const f16x4 b0 = read_tr_f16(vl + o0);
-                    const f16x4 b1 = read_tr_f16(vl + o1);
-                    const f16x8 vhi = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                    const f16x8 vlo = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    const f16x8 p_hi = __builtin_bit_cast(f16x8, ph[kbk][s2i]), p_lo = __builtin_bit_cast(f16x8, pl[kbk][s2i]);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, p_hi, o[db], 0, 0, 0);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, p_lo, o[db], 0, 0, 0);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, p_hi, o[db], 0, 0, 0);
-                }
+            for (int s2i = 0; s2i < 2; ++s2i) {
+                const int k0 = 16 * s2i + 4 * h + tq;
+                const int o0 = v_off(k0, 32 * db + tcol), o1 = v_off(k0 + 8, 32 * db + tcol);
+                const f16x4 a0 = read_tr_f16(vh + o0);
+                const f16x4 a1 = read_tr_f16(vh + o1);
+                const f16x4 b0 = read_tr_f16(vl + o0);
+                const f16x4 b1 = read_tr_f16(vl + o1);
+                const f16x8 vhi = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                const f16x8 vlo = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                const f16x8 p_hi = __builtin_bit_cast(f16x8, ph[s2i]), p_lo = __builtin_bit_cast(f16x8, pl[s2i]);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, p_hi, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, p_lo, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, p_hi, o[db], 0, 0, 0);
+            }
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's copies of the next tile have landed
         __syncthreads();
