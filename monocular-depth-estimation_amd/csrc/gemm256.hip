@@ -5,26 +5,26 @@
 // waves need them, not by where they sit in the tile:
 //     A0s = for every wave the first 64 of its 128 A rows      B0s = for every wave the first 32 of its 64 W rows
 //     A1s = the other 64 A rows                                B1s = the other 32 W rows
-// and a K-tile is multiplied in four phases of 16 MFMAs per wave (one quadrant of the wave's block each):
-//     P1: read A0s,B0s -> quadrant (0,0)    P2: read B1s -> (0,1)    P3: read A1s -> (1,1)    P4: (B0s kept) -> (1,0)
-// Every phase also issues the global_load_lds copies of ONE region of a later K-tile (2 instructions per lane):
-//     P1(t): B1s(t+1)    P2(t): A1s(t+1)    P3(t): A0s(t+2)    P4(t): B0s(t+2)
-// followed by a COUNTED wait `s_waitcnt vmcnt(8)` (the four most recent regions stay in flight) and a raw s_barrier; a second
-// barrier follows the MFMAs.  A phase is thus two barrier intervals, [reads + copy issue + wait] and [16 MFMAs], and the
-// waves 4-7 (the SIMD partners of waves 0-3) run ONE interval behind waves 0-3, so that on each SIMD the matrix pipe of
-// one wave overlaps the LDS reads of the other.
+// and a K-tile is multiplied in two phases of 32 MFMAs per wave (two quadrants of the wave's block each):
+//     PA: read A0s, B0s, B1s -> quadrants (0,0), (0,1)         PB: read A1s (B0s, B1s kept) -> quadrants (1,1), (1,0)
+// Every phase also issues global_load_lds copies for a later K-tile, into regions whose reads ended in the phase before:
+//     PA(t): A1s(t+1)  (2 instructions per lane)               PB(t): A0s(t+2), B0s(t+2), B1s(t+2)  (6 per lane)
+// followed by a COUNTED wait `s_waitcnt vmcnt(8)` (the copies of this phase and the one before stay in flight), a wait for the
+// wave's own LDS reads, and a raw s_barrier; a second barrier follows the MFMAs.  A phase is thus two barrier intervals,
+// [reads + copy issue + waits] and [32 MFMAs], and the waves 4-7 (the SIMD partners of waves 0-3) run ONE interval behind
+// waves 0-3, so that on each SIMD the matrix pipe of one wave overlaps the LDS reads of the other.  (A first form of this
+// kernel had four phases of 16 MFMAs per K-tile: twice the barriers for the same products.)
 // Invariants (two LDS buffers, K-tile t lives in buffer t & 1):
-//   * a region is re-filled no earlier than two phases after its last read: A0s,B0s are last read in P1 and refilled in
-//     P3/P4 of the same tile; B1s last read in P2, refilled in P1 of the next tile; A1s last read in P3, refilled in P2
-//     of the next tile.  Reads of phase r have returned before that wave's MFMAs of phase r, hence before it arrives at
-//     the barrier of phase r+1, which the refilling wave has passed;
-//   * a region is read no earlier than the phase after the wait that retired it: with one region issued per phase,
-//     vmcnt(8) at phase p retires everything issued up to phase p-4, and every region is issued at least 5 phases
-//     before the phase that reads it.  Each lane waits for its own copies, the barrier extends that to all lanes: the
-//     late half finishes its phase-p wait in the interval just before the early half's phase-(p+1) reads;
-//   * both hold for the staggered halves because all distances above are counted in whole phases (two intervals) and the
-//     stagger is one interval.
-// In the last two K-tiles, phases that have nothing left to issue wait with vmcnt(0) instead.
+//   * a region is re-filled in the phase after its last read (A0s, B0s, B1s: read in PA(t), refilled in PB(t); A1s: read in
+//     PB(t), refilled in PA(t+1)).  A wave's reads have RETURNED when it arrives at the first barrier of the reading phase (the
+//     lgkmcnt wait in front of it); a wave of the early half issues its refill after the second barrier of that phase, which
+//     the late half reaches as its first, and the late half's refills come later still;
+//   * a region is read no earlier than the phase after the wait that retired it: copies retire in issue order, a phase issues
+//     2 or 6 per lane alternately, so vmcnt(8) at phase p retires everything issued before phase p-1, and every region is issued
+//     three phases before the phase that reads it.  Each lane waits for its own copies, the barrier extends that to all lanes:
+//     the late half finishes its phase-p wait in the interval just before the early half's phase-(p+1) reads;
+//   * both hold for the staggered halves because the distances above are whole phases (two intervals) and the stagger is one.
+// In the last two K-tiles, phases that have nothing left to issue wait with vmcnt(2) (only A1s(t+1) in flight) or vmcnt(0).
 #include "gemm_common.h"
 
 namespace vda {
@@ -39,6 +39,7 @@ __device__ __forceinline__ void wait_vm8() { asm volatile("s_waitcnt vmcnt(8)" :
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void phase_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const
     // LDS-read / copy-issue interval.  group1 is wave-uniform by construction (readfirstlane makes that provable).
     const bool group1 = __builtin_amdgcn_readfirstlane(wave) >= 4;
 
-    // ---- prologue: all of K-tile 0, and the first two regions of K-tile 1 ---------------------------------------------------
+    // ---- prologue: all of K-tile 0, and the first three regions of K-tile 1 (A1(0), issued before them, may still be in flight) ----
     issue_a(0, 0, 0);
     issue_b(0, 0, 0);
     issue_b(1, 0, 0);
@@ -269,9 +270,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const
     if (nk > 1) {
         issue_a(0, 1, 1);
         issue_b(0, 1, 1);
+        issue_b(1, 1, 1);
         wait_vm8();
     } else {
-        wait_vm0();
+        wait_vm<2>();
     }
     phase_barrier();
     if (group1) phase_barrier();
@@ -280,28 +282,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const
         const int cur = t & 1;
         const char* buf = smem + cur * (4 * REGION);
         const bool next1 = t + 1 < nk, next2 = t + 2 < nk;
-        // P1
+        // PA: the upper half of the wave's block
         read_a(buf + R_A0 * REGION);
         read_b(buf + R_B0 * REGION, bf0);
-        if (next1) { issue_b(1, t + 1, cur ^ 1); wait_vm8(); } else { wait_vm0(); }
-        phase_barrier();
-        quadrant(0, 0, bf0);
-        phase_barrier();
-        // P2
         read_b(buf + R_B1 * REGION, bf1);
         if (next1) { issue_a(1, t + 1, cur ^ 1); wait_vm8(); } else { wait_vm0(); }
+        wait_lds();
         phase_barrier();
+        quadrant(0, 0, bf0);
         quadrant(0, 1, bf1);
         phase_barrier();
-        // P3
+        // PB: the lower half (B0s, B1s kept in registers)
         read_a(buf + R_A1 * REGION);
-        if (next2) { issue_a(0, t + 2, cur); wait_vm8(); } else { wait_vm0(); }
+        if (next2) { issue_a(0, t + 2, cur); issue_b(0, t + 2, cur); issue_b(1, t + 2, cur); wait_vm8(); }
+        else if (next1) { wait_vm<2>(); }
+        else { wait_vm0(); }
+        wait_lds();
         phase_barrier();
         quadrant(1, 1, bf1);
-        phase_barrier();
-        // P4
-        if (next2) { issue_b(0, t + 2, cur); wait_vm8(); } else { wait_vm0(); }
-        phase_barrier();
         quadrant(1, 0, bf0);
         phase_barrier();
     }
