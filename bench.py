@@ -44,7 +44,7 @@ GFLOP_PER_FRAME = {("vitl", 518, 518): 1404.67, ("vits", 518, 518): 121.28, ("vi
 # folded into qkv / fc1 (VDA_FOLD_LAYERNORM=1; off by default at ViT-L width) the form that also emits the rounded rows
 DOMINANT = ("gemm256_kernel", "f32_res32", "bf16")
 DOMINANT_FOLDED = ("gemm256_kernel", "f32_res32_emit", "bf16")
-TRAFFIC_PROFILE = "profiles/r2_vitl518_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r3_vitl518_hbm_traffic.json"
 
 
 def main():
