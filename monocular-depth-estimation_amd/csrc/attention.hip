@@ -25,9 +25,23 @@ __device__ __forceinline__ int v_off(int row, int col) { return row * 128 + ((co
 // almost every tile once the maximum has settled.
 constexpr float DEFER = 6.0f;
 
-template <int NQB>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int n_tok, int heads, int q_blocks) {
+// the two 16-bit operand types of the 32x32x16 products and of the transposed 4 x 16 block read
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+template <typename T> __device__ __forceinline__ typename Vec<T>::v4 read_tr(const char* p);
+template <> __device__ __forceinline__ bf16x4 read_tr<bf16>(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(p));
+}
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+template <> __device__ __forceinline__ f16x4 read_tr<f16>(const char* p) {      // (the builtin's own half type is not _Float16)
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(p)));
+}
+
+template <int NQB, typename T>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_tok, int heads, int q_blocks) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+    typedef typename Vec<T>::v8 v8;
+    typedef typename Vec<T>::v4 v4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     // Workgroups are handed to the 8 XCDs round-robin.  Renumber them so that each XCD works through a contiguous range of
@@ -39,16 +53,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
     const int fh = wg / q_blocks, qb = wg - fh * q_blocks;
     const int frame = fh / heads, head = fh - frame * heads;
     const int D = heads * 64, ld = 3 * D;
-    const bf16* base = qkv + (size_t)frame * n_tok * ld + head * 64;
+    const T* base = qkv + (size_t)frame * n_tok * ld + head * 64;
     const int q0 = qb * (128 * NQB) + wave * (32 * NQB);
 
     // Q fragments (B operand of S^T = K Q^T): lane (r, h) holds Q[q0 + r][16 ks + 8 h + 0..7]
-    bf16x8 qf[NQB][4];
+    v8 qf[NQB][4];
 #pragma unroll
     for (int b = 0; b < NQB; ++b) {
-        const bf16* qrow = base + (size_t)min(q0 + 32 * b + r, n_tok - 1) * ld + 8 * h;
+        const T* qrow = base + (size_t)min(q0 + 32 * b + r, n_tok - 1) * ld + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
+        for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *reinterpret_cast<const v8*>(qrow + 16 * ks);
     }
 
     // staging: per tile every thread copies 2 K pieces and 2 V pieces of 16 bytes straight from global memory into LDS
@@ -56,8 +70,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
     // of tile_off() / v_off() are applied to the SOURCE chunk each lane fetches: the lane that fills position sc of a row
     // fetches chunk sc ^ swizzle(row), which is what those functions' readers expect to find there.
     const int srow = tid >> 3, sc = tid & 7;
-    const bf16* kbase = base + D;
-    const bf16* vbase = base + 2 * D;
+    const T* kbase = base + D;
+    const T* vbase = base + 2 * D;
     auto stage_tile = [&](int kt, int buf) {
         char* kb = smem + buf * 16384;
         char* vb = kb + 8192;
@@ -113,13 +127,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
         for (int kbk = 0; kbk < 2; ++kbk) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + tile_off(32 * kbk + r, 2 * ks + h));
+                const v8 kf = *reinterpret_cast<const v8*>(kb + tile_off(32 * kbk + r, 2 * ks + h));
 #pragma unroll
                 for (int b = 0; b < NQB; ++b)
-                    s[b][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][ks], ks == 0 ? negm[b] : s[b][kbk], 0, 0, 0);
+                    s[b][kbk] = mfma32(kf, qf[b][ks], ks == 0 ? negm[b] : s[b][kbk]);
             }
         }
-        bf16x8 pf[NQB][2][2];
+        v8 pf[NQB][2][2];
 #pragma unroll
         for (int b = 0; b < NQB; ++b) {
             if (kt == nkt - 1) {   // keys past the end of the sequence
@@ -160,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
                 for (int i = 0; i < 16; ++i) {
                     const float pv = __builtin_amdgcn_exp2f(s[b][kbk][i]);
                     ps[i & 3] += pv;
-                    pf[b][kbk][i >> 3][i & 7] = (bf16)pv;
+                    pf[b][kbk][i >> 3][i & 7] = (T)pv;
                 }
             l_run[b] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
         }
@@ -172,13 +186,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int k0 = 32 * kbk + 16 * s2 + 4 * h + tq;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (bf16x4 __attribute__((address_space(3)))*)(vb + v_off(k0, 32 * db + tcol)));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (bf16x4 __attribute__((address_space(3)))*)(vb + v_off(k0 + 8, 32 * db + tcol)));
-                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const v4 lo = read_tr<T>(vb + v_off(k0, 32 * db + tcol));
+                    const v4 hi = read_tr<T>(vb + v_off(k0 + 8, 32 * db + tcol));
+                    const v8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-                    for (int b = 0; b < NQB; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][kbk][s2], o[b][db], 0, 0, 0);
+                    for (int b = 0; b < NQB; ++b) o[b][db] = mfma32(vf, pf[b][kbk][s2], o[b][db]);
                 }
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's copies of the next tile have landed
@@ -191,14 +203,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
         const float inv = 1.0f / l_tot;
         const int q = q0 + 32 * b + r;
         if (q < n_tok) {
-            bf16* orow = out + ((size_t)frame * n_tok + q) * D + head * 64 + 4 * h;
+            T* orow = out + ((size_t)frame * n_tok + q) * D + head * 64 + 4 * h;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const bf16x4 v = {(bf16)(o[b][db][4 * g] * inv), (bf16)(o[b][db][4 * g + 1] * inv),
-                                      (bf16)(o[b][db][4 * g + 2] * inv), (bf16)(o[b][db][4 * g + 3] * inv)};
-                    *reinterpret_cast<bf16x4*>(orow + 32 * db + 8 * g) = v;
+                    const v4 v = {(T)(o[b][db][4 * g] * inv), (T)(o[b][db][4 * g + 1] * inv),
+                                  (T)(o[b][db][4 * g + 2] * inv), (T)(o[b][db][4 * g + 3] * inv)};
+                    *reinterpret_cast<v4*>(orow + 32 * db + 8 * g) = v;
                 }
         }
     }
@@ -210,9 +222,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
 // the split (q, k, v by QKV_SCALE, probabilities, which reach 2^DEFER = 64, by P_SCALE) so that the low halves are normal
 // numbers, and the sums are scaled back.  Same structure as attn_kernel<1> otherwise.
 constexpr float QKV_SCALE = 16.f, P_SCALE = 256.f;
-typedef short i16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f16x4 read_tr_f16(const char* p) {     // transposed 4 x 16 block read of 16-bit patterns
-    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(p)));
+    return read_tr<f16>(p);
 }
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n_tok,
                                                             int heads, int q_blocks) {
@@ -582,7 +593,7 @@ extern "C" int vda_attention_pairs(const void* qkv2, void* out3, int frames, int
 
 extern "C" int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, int dtype, void* stream) {
     if (!qkv || !out || frames <= 0 || n_tok <= 0 || heads <= 0) return VDA_EINVAL;
-    if (dtype != VDA_T_BF16 && dtype != VDA_T_F32) return VDA_EINVAL;
+    if (dtype != VDA_T_BF16 && dtype != VDA_T_F16 && dtype != VDA_T_F32) return VDA_EINVAL;
     if (dtype == VDA_T_F32) {
         const int qb = (n_tok + 127) / 128;
         if ((long)frames * heads * qb > 0x7fffffffL) return VDA_ESHAPE;
@@ -596,11 +607,14 @@ extern "C" int vda_attention(const void* qkv, void* out, int frames, int n_tok, 
     const int q_blocks = (n_tok + 128 * nqb - 1) / (128 * nqb);
     if ((long)frames * heads * q_blocks > 0x7fffffffL) return VDA_ESHAPE;
     dim3 grid(frames * heads * q_blocks);
-    if (nqb == 2)
-        hipLaunchKernelGGL(attn_kernel<2>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           reinterpret_cast<const bf16*>(qkv), reinterpret_cast<bf16*>(out), n_tok, heads, q_blocks);
-    else
-        hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           reinterpret_cast<const bf16*>(qkv), reinterpret_cast<bf16*>(out), n_tok, heads, q_blocks);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define VDA_ATTN(NQB, T) hipLaunchKernelGGL((attn_kernel<NQB, T>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(qkv), \
+                                            reinterpret_cast<T*>(out), n_tok, heads, q_blocks)
+    if (dtype == VDA_T_F16) {
+        if (nqb == 2) VDA_ATTN(2, f16); else VDA_ATTN(1, f16);
+    } else {
+        if (nqb == 2) VDA_ATTN(2, bf16); else VDA_ATTN(1, bf16);
+    }
+#undef VDA_ATTN
     return hip_rc(hipGetLastError());
 }

@@ -300,13 +300,16 @@ extern "C" int vda_bilinear_f32(const float* x, float* out, int frames, int in_h
 
 extern "C" int vda_im2col_patch14(const float* x, void* out, int frames, int H, int W, int ldk, int out_type, void* stream) {
     if (!x || !out || frames <= 0 || H <= 0 || W <= 0) return VDA_EINVAL;
-    if (out_type != VDA_T_BF16 && out_type != VDA_T_F32) return VDA_EINVAL;
+    if (out_type != VDA_T_BF16 && out_type != VDA_T_F16 && out_type != VDA_T_F32) return VDA_EINVAL;
     if (H % 14 != 0 || W % 14 != 0 || ldk % 64 != 0 || ldk < 588) return VDA_ESHAPE;
     const int hp = H / 14, wp = W / 14;
     const size_t total = (size_t)frames * hp * wp * (ldk / 8);
     if (out_type == VDA_T_F32)
         hipLaunchKernelGGL(im2col_patch14_kernel<float>, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                            x, reinterpret_cast<float*>(out), H, W, hp, wp, ldk, total);
+    else if (out_type == VDA_T_F16)
+        hipLaunchKernelGGL(im2col_patch14_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           x, reinterpret_cast<f16*>(out), H, W, hp, wp, ldk, total);
     else
         hipLaunchKernelGGL(im2col_patch14_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                            x, reinterpret_cast<bf16*>(out), H, W, hp, wp, ldk, total);

@@ -48,7 +48,7 @@ class Engine:
         self.split_enc, self.split_head, self.split_tail = packed.split_enc, packed.split_head, packed.split_tail
         self.split = self.split_enc
         self.hdt = packed.head_dtype         # storage/operand type of the DPT head and the temporal modules
-        self.edt = torch.float32 if self.split_enc else BF16      # storage type of the encoder's GEMM operands
+        self.edt = packed.encoder_dtype      # storage type of the encoder's GEMM operands (fp32: operand pieces instead)
         # fp32 storage: the power of two every activation is multiplied by before it is split into IEEE halves.  16 keeps a
         # normal low half for values down to 2^-7 and holds |values| below 4094; a window in which some scaled value leaves
         # the half range (``sat`` is set by the kernel that saw it) is run again with the scale divided by 16, and the lower

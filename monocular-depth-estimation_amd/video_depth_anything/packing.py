@@ -68,6 +68,8 @@ def resample_pos_embed(pos_embed, hp, wp):
     return np.concatenate([pe[:1], out.reshape(hp * wp, -1).astype(np.float32)], axis=0)
 
 
+# 16-bit operand type of the encoder in the 16-bit mode ("bf16" or "fp16"; same MFMA rate, 8 against 11 significand bits)
+ENCODER_DTYPE = {"bf16": BF16, "fp16": torch.float16}[os.environ.get("VDA_ENCODER_DTYPE", "bf16")]
 SPLIT_DTYPE = torch.float16      # piece type of the fp32 mode's hi/lo operands (torch.bfloat16: 8-bit pieces, no scaling)
 ACT_SPLIT_SCALE = 16.0           # power of two every fp32 activation is multiplied by before it is split into halves:
 #                                  values down to 2^-7 keep a normal low half, values up to 4094 fit the high half
@@ -132,13 +134,18 @@ class PackedWeights:
     """Device-resident kernel-layout weights of one model.  ``precision`` "fp32" packs every matrix as 16-bit hi/lo triples
     (``SplitWeight``) for the fp32 storage mode (``head_dtype`` is then ignored); see PRECISIONS for the mixed forms."""
 
-    def __init__(self, sd, encoder, features, out_channels, device, head_dtype=torch.float16, precision="half", layout=None):
+    def __init__(self, sd, encoder, features, out_channels, device, head_dtype=torch.float16, precision="half", layout=None,
+                 encoder_dtype=None):
         self.device = device
         self.precision = precision
         self.layout = PIECES_LAYOUT if layout is None else layout        # of the fp32 mode's operand pieces (PIECES_*)
         split_weight = lambda t: SplitWeight(t, layout=self.layout)  # noqa: E731
         self.split_enc, self.split_head, self.split_tail = PRECISIONS[precision]
         self.head_dtype = torch.float32 if self.split_head else head_dtype
+        encoder_dtype = encoder_dtype or ENCODER_DTYPE
+        if encoder_dtype not in (torch.float16, BF16):
+            raise ValueError("encoder_dtype: torch.float16 or torch.bfloat16")
+        self.encoder_dtype = torch.float32 if self.split_enc else encoder_dtype
         self.encoder = encoder
         D, depth, heads, taps = ENCODERS[encoder]
         self.D, self.depth, self.heads, self.taps = D, depth, heads, taps
@@ -150,7 +157,7 @@ class PackedWeights:
         self._pos_cache = {}
         g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32)  # noqa: E731
         f32 = lambda t: t.contiguous()  # noqa: E731
-        bf = split_weight if self.split_enc else (lambda t: t.to(BF16).contiguous())
+        bf = split_weight if self.split_enc else (lambda t: t.to(encoder_dtype).contiguous())
         hd_ = split_weight if self.split_head else (lambda t: t.to(head_dtype).contiguous())
         hd_all = hd_
 

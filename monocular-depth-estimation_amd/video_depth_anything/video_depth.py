@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import hip
 from .engine import Engine
-from .packing import PRECISIONS, PackedWeights
+from .packing import ENCODER_DTYPE, PRECISIONS, PackedWeights
 from .spec import ENCODERS, state_dict_spec
 from .windows import INFER_LEN, KEYFRAMES, OVERLAP
 
@@ -57,6 +57,9 @@ class VideoDepthAnything(nn.Module):
         # rate as bf16 and 3 more mantissa bits; with bf16 here the depth error is 1.6e-2 max-relative (above the 1e-2
         # bound), with fp16 it is set by the bf16 encoder alone.  The reference's own GPU default is fp16 autocast.
         self.head_dtype = torch.float16
+        # 16-bit operand type of the encoder's products and stored activations (the residual stream, the norms' statistics,
+        # softmax and all accumulators are fp32 either way).  VDA_ENCODER_DTYPE=fp16|bf16 sets the default.
+        self.encoder_dtype = ENCODER_DTYPE
         # "half": 16-bit activations (bf16 encoder, head_dtype head).  "fp32": fp32 activations and three-term IEEE-half
         # hi/lo products on the same matrix cores (about 2^-21 per product) -- what ``infer_video_depth(fp32=True)``
         # selects, the counterpart of the reference running without autocast (video_depth.py:136).
@@ -112,7 +115,7 @@ class VideoDepthAnything(nn.Module):
         if self._flat is None:
             self._flat = list(self.state_dict(keep_vars=True).values())
         p = self.pretrained.cls_token
-        return (p.device, self.head_dtype, self.pieces_layout, tuple((t.data_ptr(), t._version) for t in self._flat))
+        return (p.device, self.head_dtype, self.encoder_dtype, self.pieces_layout, tuple((t.data_ptr(), t._version) for t in self._flat))
 
     def _ensure_engine(self):
         dev = self.pretrained.cls_token.device
@@ -125,7 +128,7 @@ class VideoDepthAnything(nn.Module):
         cached = self._engines.get(self.precision)
         if cached is None or cached[0] != key:
             packed = PackedWeights(self.state_dict(), self.encoder, self.features, self.out_channels, dev, self.head_dtype,
-                                   precision=self.precision, layout=self.pieces_layout)
+                                   precision=self.precision, layout=self.pieces_layout, encoder_dtype=self.encoder_dtype)
             cached = (key, Engine(packed))
             self._engines[self.precision] = cached
         return cached[1]

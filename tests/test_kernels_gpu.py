@@ -358,45 +358,52 @@ def softmax2(scores):
     return torch.softmax(scores * math.log(2.0), -1)
 
 
+ATTN_TYPES = [BF, torch.float16]
+ATTN_TOL = {BF: 1.2e-2, torch.float16: 2e-3}
+
+
 @pytest.mark.parametrize("frames,n_tok,heads", [(2, 1370, 6), (3, 64, 2), (1, 129, 16), (2, 36, 1), (1, 4100, 2), (1, 5477, 1)])
-def test_attention(frames, n_tok, heads):
+@pytest.mark.parametrize("dt", ATTN_TYPES)
+def test_attention(frames, n_tok, heads, dt):
     D = heads * 64
-    qkv = rnd((frames, n_tok, 3 * D), 1)
-    out = torch.full((frames, n_tok, D), float("nan"), dtype=BF, device=DEV)
+    qkv = rnd((frames, n_tok, 3 * D), 1, 1.0, dt)
+    out = torch.full((frames, n_tok, D), float("nan"), dtype=dt, device=DEV)
     hip.attention(qkv, out, frames, n_tok, heads)
     q, k, v = qkv.float().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
     want = (softmax2(q @ k.transpose(-1, -2)) @ v).transpose(1, 2).reshape(frames, n_tok, D)
-    close(out, want, 1.2e-2, "attention")       # probabilities are rounded to bf16 before the second product
+    close(out, want, ATTN_TOL[dt], "attention")       # probabilities are rounded to the operand type before the second product
 
 
 @pytest.mark.parametrize("n_tok", [200, 4200])       # 32 and 64 queries per wave
-def test_attention_sharp_softmax_rescale(n_tok):
+@pytest.mark.parametrize("dt", ATTN_TYPES)
+def test_attention_sharp_softmax_rescale(n_tok, dt):
     """One key dominates from a later K/V tile on: forces the running-max rescale branch."""
     frames, heads = 1, 1
-    qkv = rnd((frames, n_tok, 192), 2, 0.5)
+    qkv = rnd((frames, n_tok, 192), 2, 0.5, dt)
     qkv[0, 150, 64:128] = qkv[0, 10, 0:64] * 12          # key 150 aligned with query 10
     qkv[0, n_tok - 7, 64:128] = qkv[0, 45, 0:64] * 12    # and one in the last tile, for a query of the second block
-    out = torch.empty((frames, n_tok, 64), dtype=BF, device=DEV)
+    out = torch.empty((frames, n_tok, 64), dtype=dt, device=DEV)
     hip.attention(qkv, out, frames, n_tok, heads)
     q, k, v = qkv.float().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
     want = (softmax2(q @ k.transpose(-1, -2)) @ v).transpose(1, 2).reshape(frames, n_tok, 64)
-    close(out, want, 1.2e-2, "attention rescale")
+    close(out, want, ATTN_TOL[dt], "attention rescale")
 
 
 @pytest.mark.parametrize("n_tok", [130, 4200])
 @pytest.mark.parametrize("offset", [-300.0, 300.0])
-def test_attention_scores_far_from_zero(n_tok, offset):
+@pytest.mark.parametrize("dt", ATTN_TYPES)
+def test_attention_scores_far_from_zero(n_tok, offset, dt):
     """Every score of a query is near `offset`: the first tile must set the running maximum whatever its sign (2^-300 and
     2^300 are not fp32 numbers), and later tiles stay relative to it."""
     frames, heads = 1, 1
-    qkv = rnd((frames, n_tok, 192), 5, 0.5)
+    qkv = rnd((frames, n_tok, 192), 5, 0.5, dt)
     qkv[..., 63] = 16.0                                   # q[63] = 16
-    qkv[..., 127] = offset / 16.0                         # k[63]: adds `offset` to every score (exact in bf16)
-    out = torch.full((frames, n_tok, 64), float("nan"), dtype=BF, device=DEV)
+    qkv[..., 127] = offset / 16.0                         # k[63]: adds `offset` to every score (exact in both operand types)
+    out = torch.full((frames, n_tok, 64), float("nan"), dtype=dt, device=DEV)
     hip.attention(qkv, out, frames, n_tok, heads)
     q, k, v = qkv.double().reshape(frames, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
     want = (softmax2(q @ k.transpose(-1, -2)) @ v).transpose(1, 2).reshape(frames, n_tok, 64).float()
-    close(out, want, 1.2e-2, "attention, shifted scores")
+    close(out, want, ATTN_TOL[dt], "attention, shifted scores")
 
 
 @pytest.mark.parametrize("rows,C", [(1370 * 2, 1024), (100, 384), (37, 64), (50, 192)])

@@ -1,6 +1,7 @@
 """Where the error of the 720p ViT-L video (the GPU test with the thinnest margin under the 1e-2 bound) comes from: the same
 video through every precision form (packing.PRECISIONS), worst per-frame floored max-rel, the value of the reference at the
-worst pixel relative to the frame's maximum, and the error there relative to the maximum.    python tools/margin_720p.py"""
+worst pixel relative to the frame's maximum, and the error there relative to the maximum.
+    python tools/margin_720p.py [forms ...]          (VDA_ENCODER_DTYPE=fp16|bf16 selects the 16-bit encoder type)"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +24,7 @@ from test_model_gpu import synth_frames  # noqa: E402  (the frames of the test i
 frames = synth_frames(34, 720, 1280, 4242)
 want = O.infer_video_depth(None, list(frames), "vitl", batch_size=32, input_size=518,
                            forward_fn=lambda inp: O.forward(sd_dev, inp.cuda(), "vitl"))
-for mode in ("half", "tail32", "head32", "enc32", "fp32"):
+for mode in (sys.argv[1:] or ("half", "tail32", "head32", "enc32", "fp32")):
     m.precision = mode
     got, _ = m.infer_video_depth(list(frames), 30, input_size=518, device="cuda", batch_size=32)
     per = [O.max_rel_err(got[t], want[t]) for t in range(34)]
