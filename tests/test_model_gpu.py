@@ -240,6 +240,48 @@ def test_forward_with_checkpoint_like_outliers_in_16_bit_mode(golden_dir, vits_o
     assert mr <= MAX_REL and ar <= ABS_REL
 
 
+# measured with IEEE-half encoder operands: goldens 1.7-2.5e-3 (bf16: 4-8e-3), ViT-L 518x924 2.8e-3 (bf16: 7-9e-3)
+FP16_ENCODER_MAX_REL = 5e-3
+
+
+@pytest.mark.parametrize("name,shape,seed", [("T32", (1, 32, 3, 70, 98), 41), ("B2T3", (2, 3, 3, 56, 42), 43)])
+def test_forward_with_fp16_encoder_operands(golden_dir, vits, vits_outliers, name, shape, seed):
+    """``model.encoder_dtype = torch.float16``: the encoder's products on IEEE-half instead of bf16 operands (three more
+    significand bits at the same matrix-core rate; the reference's own GPU default is fp16 autocast).  The error against the
+    reference goldens is about a third of the bf16 figure, and the checkpoint-like outlier profile stays finite and in bounds
+    (the residual stream is fp32 either way; products that leave the half range saturate at 65504)."""
+    x = torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32)).cuda()
+    for model, gname, bound in ((vits[0], "g4_forward.npz", FP16_ENCODER_MAX_REL), (vits_outliers, "g4c_forward_outliers.npz", MAX_REL)):
+        g = np.load(os.path.join(golden_dir, gname))
+        saved = model.encoder_dtype
+        try:
+            model.encoder_dtype = torch.float16
+            out = model(x).cpu().numpy()
+            assert model._ensure_engine().edt == torch.float16
+        finally:
+            model.encoder_dtype = saved
+        assert np.isfinite(out).all()
+        mr, ar = report(f"{gname} {name}, fp16 encoder operands", out, g[name])
+        assert mr <= bound and ar <= ABS_REL
+
+
+def test_vitl_wide_frame_with_fp16_encoder_operands(vitl):
+    """ViT-L at the 16:9 network size (the shape with the thinnest margin under bf16 operands) with IEEE-half encoder operands."""
+    m, sd_dev = vitl
+    x = torch.from_numpy(np.random.RandomState(3).standard_normal((1, 4, 3, 518, 924)).astype(np.float32)).cuda()
+    saved = m.encoder_dtype
+    try:
+        m.encoder_dtype = torch.float16
+        got = m(x).cpu().numpy()
+    finally:
+        m.encoder_dtype = saved
+    want = oracle_on_device(sd_dev, x, "vitl")
+    worst = max(O.max_rel_err(got[0, t], want[0, t]) for t in range(4))
+    ar = O.abs_rel(got, want)
+    print(f"vitl 518x924 T=4, fp16 encoder operands: worst per-frame max_rel={worst:.3e} abs_rel={ar:.3e}")
+    assert worst <= FP16_ENCODER_MAX_REL and ar <= ABS_REL
+
+
 def test_forward_with_checkpoint_like_outliers_in_fp32_mode_lowers_the_operand_scale(golden_dir, vits_outliers):
     """fp32 storage mode: with the default operand scale (16) the head channel at 5.5e4 leaves the range of the IEEE-half
     pieces.  The kernel that splits it raises the saturation flag; the engine warns, divides the scale by 16 and computes the
