@@ -151,6 +151,7 @@ def main():
     headline = (args.encoder, H, W, T, args.precision) == ("vitl", 518, 518, 32, "half")
 
     out = None
+    enc16 = "f16" if model.encoder_dtype == torch.float16 else "bf16"       # VDA_ENCODER_DTYPE=fp16 selects IEEE-half operands
     if rank == 0:
         fps = world * args.steps * T / dt
         out = {
@@ -158,13 +159,13 @@ def main():
             else f"frames/sec ({args.encoder}, {T}-frame windows at {H}x{W}, precision {args.precision})",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "half" else "f32 (3 x fp16 hi/lo MFMA passes)", "data": "synthetic",
+            "dtype": enc16 if args.precision == "half" else "f32 (3 x fp16 hi/lo MFMA passes)", "data": "synthetic",
             "config": {"workload": f"Video-Depth-Anything-{'Large (ViT-L)' if args.encoder == 'vitl' else 'Small (ViT-S)'} "
                                    f"forward, 1x{T}x3x{H}x{W} window resident in HBM, random-init weights",
                        "windows_per_step_per_gpu": 1, "parallelism": f"window-parallel x{world}",
                        "encoder_streams": model.encoder_streams,
                        "encoder_layernorms": "folded into qkv / fc1" if model._ensure_engine().folds_layernorms() else "separate pass",
-                       "operands": "encoder bf16 MFMA, head fp16 MFMA, fp32 accumulate" if args.precision == "half"
+                       "operands": f"encoder {enc16} MFMA, head fp16 MFMA, fp32 accumulate" if args.precision == "half"
                        else "fp32 activations; every product hi*hi + lo*hi + hi*lo on fp16 MFMA, fp32 accumulate",
                        "parity": "16-bit mode: max-rel <= 1e-2 / AbsRel <= 0.5 % on depth maps without clamped pixels, 4-8e-3 of "
                                  "the map maximum absolute where pixels are clamped to 0; --precision fp32 meets 1e-2 / 0.5 % "
