@@ -152,7 +152,8 @@ int vda_gemm_kernel_choice(const VdaGemmArgs* args);
  * projection, q already multiplied by log2(e) * 64^-1/2 (VDA_ATTENTION_Q_SCALE): the scores are then base-2 logarithms
  * and the probabilities 2^(score - max), which is what the hardware's exponential computes; out:
  * [frames][n_tok][heads*64]; both of type dtype.
- * dtype VDA_T_BF16: bf16 operands.  dtype VDA_T_F32: fp32 in and out; q, k, v and the probabilities are split into
+ * dtype VDA_T_BF16 or VDA_T_F16: 16-bit operands of that type (probabilities are rounded to it for the second product).
+ * dtype VDA_T_F32: fp32 in and out; q, k, v and the probabilities are split into
  * IEEE-half hi/lo pairs on the fly (after scaling by powers of two) and every product is the three-term hi/lo sum.
  * Replaces attention.py:51-59 of the reference (dinov2_layers).
  * ------------------------------------------------------------------------------------------------------------- */
@@ -235,7 +236,7 @@ int vda_bilinear_nhwc_pieces(const float* x, void* out, int frames, int in_h, in
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Patch embedding front end.
- * vda_im2col_patch14: fp32 NCHW frames [frames][3][H][W] -> rows [frames*hp*wp][ldk] of out_type BF16 or F32, k = c*196 + ky*14 + kx
+ * vda_im2col_patch14: fp32 NCHW frames [frames][3][H][W] -> rows [frames*hp*wp][ldk] of out_type BF16, F16 or F32, k = c*196 + ky*14 + kx
  *   (the flattening order of the conv weight [D][3][14][14]), columns 588..ldk-1 zero.  ldk % 64 == 0, ldk >= 588.
  * vda_assemble_tokens: x[f][0] = cls + pos[0]; x[f][1+p] = tok[f*hw+p] + pos[1+p]  (fp32)   (dinov2.py:218-219).
  * Replaces patch_embed.py:76-78 together with vda_gemm.
