@@ -258,7 +258,7 @@ int check_args(const VdaGemmArgs* args) {
     if (a.ab_pairs != 0 && a.ab_pairs != 1) return VDA_EINVAL;
     if (a.ab_pairs && (a.relu_in || a.row_stat || a.out16 || a.cin_used || a.up_h)) return VDA_ESHAPE;
     if (a.ab_type != VDA_T_BF16 && a.ab_type != VDA_T_F16) return VDA_EINVAL;
-    if (a.tile_cfg < 0 || a.tile_cfg > 4) return VDA_EINVAL;
+    if (a.tile_cfg < 0 || a.tile_cfg > 3) return VDA_EINVAL;
     // folded LayerNorm: consumer side (row_stat / w_colsum) and producer side (out16 / row_part)
     if ((a.row_stat != nullptr) != (a.w_colsum != nullptr)) return VDA_EINVAL;
     if (a.row_stat) {
@@ -306,7 +306,7 @@ int choose_kernel(const VdaGemmArgs& a) {
     // win, 96 vs 105 us at M = 43840, K = 1536)
     const bool wide = a.N >= 192 && 5 * a.N >= 4 * 256 * ((a.N + 255) / 256);
     const bool fills = a.K >= 1024 ? tiles256 >= 160 : a.K >= 512 ? tiles256 >= 1024 : a.K >= 256 && tiles256 >= 1800;
-    const bool big = a.tile_cfg == 2 || a.tile_cfg == 4 || (a.tile_cfg == 0 && wide && fills);
+    const bool big = a.tile_cfg == 2 || (a.tile_cfg == 0 && wide && fills);
     return big ? VDA_KERNEL_256x256 : VDA_KERNEL_128x128;
 }
 

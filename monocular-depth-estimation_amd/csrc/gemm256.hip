@@ -25,6 +25,11 @@
 //     the late half finishes its phase-p wait in the interval just before the early half's phase-(p+1) reads;
 //   * both hold for the staggered halves because the distances above are whole phases (two intervals) and the stagger is one.
 // In the last two K-tiles, phases that have nothing left to issue wait with vmcnt(2) (only A1s(t+1) in flight) or vmcnt(0).
+// Why eight waves and not four with 128 x 128 each (which would halve the LDS reads per product and need no stagger): an
+// LDS-DMA instruction costs the issuing wave 60-180 cycles, and a K-tile needs 64 of them per workgroup.  With a partner wave
+// on the SIMD that cost runs beside the partner's MFMAs; with one wave per SIMD it is added to the wave's own 128 MFMAs
+// (measured on a bit-equal four-wave build of this kernel: 292 against 229 us at M = 43840, N = 3072, K = 1024).  The split of
+// the copies over the phases is the measured optimum too: 4 + 4 per lane is 3 % slower, 0 + 8 is 4-7 % slower.
 #include "gemm_common.h"
 
 namespace vda {
@@ -320,166 +325,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const VdaGemmArgs p, const
     gemm_epilogue_spec<SPEC, T, 8, 4, LN>(p, acc, m0 + wm * 128 + frow, n0 + wn * 64 + fq * 4, fq, smem + wave * 16384, nullptr, rs);
 }
 
-// ---- one wave per SIMD: 4 waves (2 x 2), each owning a 128 x 128 block = 8 x 8 MFMA tiles (256 accumulator registers) ----------
-// A wave has the SIMD's whole register file (512 per lane), so it can hold the fragments of the NEXT k-step beside the
-// accumulators and overlap its own LDS reads and copies with its own MFMAs: no partner wave, no stagger, ONE barrier per K-tile.
-// A fragment read feeds 8 MFMAs (4 in the 8-wave kernel): half the LDS read traffic per product.
-//   K-tile t lives in stage t & 1 (A: 256 rows x 128 bytes, then W: 256 rows x 128 bytes).
-//   step (t, 0): 64 MFMAs on the fragments of k-step 0, while the fragments of k-step 1 are read;
-//   then: the wave's reads have returned (stage t & 1 may be overwritten once every wave says so), its copies of K-tile t+1
-//   have landed; barrier;
-//   step (t, 1): 64 MFMAs on k-step 1, while the fragments of (t+1, 0) are read from the other stage and the copies of
-//   K-tile t+2 are issued into stage t & 1.
-// Products are added per accumulator in the same order as in the other GEMM kernels (k-steps ascending): same bits.
-// The accumulators fill the AGPR half of the register file exactly (64 tiles x 4 registers), so the product must overwrite
-// its own C operand: written as inline assembly with a read-write AGPR operand, because the allocator, left to itself, gives
-// many products a destination apart from their source and spills the difference.
-__device__ __forceinline__ void mfma16_in_place(f32x4& c, bf16x8 w, bf16x8 a) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(a));
-}
-__device__ __forceinline__ void mfma16_in_place(f32x4& c, f16x8 w, f16x8 a) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(a));
-}
-
-template <int SPEC, typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256w_kernel(const VdaGemmArgs p, const GemmTiles gt) {
-    typedef typename Vec<T>::v8 frag_t;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE = 65536, W_OFF = 32768;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    int tm, tn;
-    tile_of_workgroup(gt, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
-
-    // staging: one copy instruction of the workgroup covers 32 rows x 128 bytes (lane-linear in LDS, swizzle on the source chunk)
-    const int srow = tid >> 3;
-    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
-    unsigned a_off[8], w_off[8];                 // element offsets of this lane's piece of rows i * 32 + srow (checked < 2^31 by the launcher)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        a_off[i] = (unsigned)min(m0 + i * 32 + srow, p.M - 1) * (unsigned)p.lda + schunk * 8;
-        w_off[i] = (unsigned)min(n0 + i * 32 + srow, p.N - 1) * (unsigned)p.K + schunk * 8;
-    }
-    const T* a_base = reinterpret_cast<const T*>(p.a);
-    const T* w_base = reinterpret_cast<const T*>(p.w);
-    auto issue_a = [&](int i, int kt, int stage) { glds16(a_base + kt * BK + a_off[i], smem + stage * STAGE + i * 4096 + wave * 1024); };
-    auto issue_w = [&](int i, int kt, int stage) { glds16(w_base + kt * BK + w_off[i], smem + stage * STAGE + W_OFF + i * 4096 + wave * 1024); };
-
-    f32x4 acc[2][8][4];                          // [column half][m-tile][n-tile within the half]
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-    const int frow = lane & 15, fq = lane >> 4;
-    constexpr bool LN = SPEC == EPI_SPEC_OWN_LN || SPEC == EPI_SPEC_OWN_GELU_LN;
-    f32x2 rs[LN ? 8 : 1];
-    if constexpr (LN) rowstat_prefetch<8>(p, rs, m0 + wm * 128 + frow);
-    // fragment offsets: m-tile i of the wave is i * 2048 bytes on, k-step 1 is the chunk index with bit 2 flipped
-    const int fa0 = tile_off(wm * 128 + frow, fq), fb0 = W_OFF + tile_off(wn * 128 + frow, fq);
-
-    frag_t fa[2][8], fb[2][8];
-    auto read_a = [&](int i, int ks, int stage) { fa[ks][i] = *reinterpret_cast<const frag_t*>(smem + stage * STAGE + ((fa0 + i * 2048) ^ (ks << 6))); };
-    auto read_b = [&](int j, int ks, int stage) { fb[ks][j] = *reinterpret_cast<const frag_t*>(smem + stage * STAGE + ((fb0 + j * 2048) ^ (ks << 6))); };
-    // one k-step: 8 groups of 8 MFMAs (m-tile i against all 8 n-tiles); behind group i the reads (and copies) that run beside
-    // the following groups are issued, and the scheduler is told to leave that order alone.  The 16 fragment reads of the next
-    // k-step go out behind groups 0..3 (W fragments first: the next step's first group needs all of them), so that the
-    // groups 4..7 cover their latency.
-    auto step = [&](int ks, auto&& side_work) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) mfma16_in_place(acc[j >> 2][i][j & 3], fb[ks][j], fa[ks][i]);
-            __builtin_amdgcn_sched_barrier(0);
-            side_work(i);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto read_next = [&](int i, int ks, int stage) {       // quarter i of the 16 fragment reads of k-step (stage, ks)
-        if (i < 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) read_b(4 * i + j, ks, stage);
-        } else if (i < 4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) read_a(4 * (i - 2) + j, ks, stage);
-        }
-    };
-    // prologue: K-tiles 0 and 1 on their way, the fragments of (0, 0) in registers
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { issue_a(i, 0, 0); issue_w(i, 0, 0); }
-    if (nk > 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { issue_a(i, 1, 1); issue_w(i, 1, 1); }
-        wait_vm<16>();
-    } else {
-        wait_vm0();
-    }
-    phase_barrier();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { read_a(i, 0, 0); read_b(i, 0, 0); }
-
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        __builtin_amdgcn_s_setprio(1);
-        step(0, [&](int i) { read_next(i, 1, cur); });
-        wait_lds();
-        wait_vm0();
-        phase_barrier();
-        // (after the last K-tile the reads fetch bytes nobody uses: straight-line code keeps every accumulator in its register)
-        const bool more = t + 2 < nk;
-        step(1, [&](int i) {
-            read_next(i, 0, cur ^ 1);
-            if (more) { issue_a(i, t + 2, cur); issue_w(i, t + 2, cur); }
-        });
-        __builtin_amdgcn_s_setprio(0);
-    }
-    // (the compiler does not know the assembly above for matrix instructions: the wait states between the last of them and
-    // the first read of an accumulator are spelled out)
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    phase_barrier();          // every wave's LDS reads are over: the epilogues reuse the tile buffers wave by wave (32 KiB each)
-
-    char* own = smem + wave * 32768;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int m_wave0 = m0 + wm * 128, n_wave0 = n0 + wn * 128 + h * 64;
-        if (SPEC == EPI_SPEC_F32_RES32 || SPEC == EPI_SPEC_F32_RES32_EMIT) {
-            const bool aligned = ((p.ldr | p.ldc) & 3) == 0 && (((uintptr_t)p.resid | (uintptr_t)p.out) & 15) == 0;
-            if (__builtin_amdgcn_readfirstlane(m_wave0 + 128 <= p.M && n_wave0 + 64 <= p.N && aligned)) {
-                scale_acc<8, 4>(p, acc[h]);
-                epilogue_res32_dma<SPEC == EPI_SPEC_F32_RES32_EMIT, T>(p, acc[h], m_wave0, n_wave0, own + h * 16384);
-                continue;
-            }
-        }
-        gemm_epilogue_spec<SPEC, T, 8, 4, LN>(p, acc[h], m_wave0 + frow, n_wave0 + fq * 4, fq, own + h * 16384, nullptr, rs);
-    }
-}
-
-// the forms the encoder spends its time in; VDA_EUNSUPPORTED_HERE (positive, not an error code of the ABI) = not this kernel's
-constexpr int W4_NOT_HERE = 1 << 30;
-template <typename T>
-int launch_w4(const VdaGemmArgs& a, hipStream_t s) {
-    GemmTiles gt{(a.M + 255) / 256, (a.N + 255) / 256};
-    const int lds = 2 * 65536;
-    dim3 grid(gt.tiles_m * gt.tiles_n);
-#define VDA_CASE_W4(SPEC)                                                                                    \
-    case SPEC: {                                                                                             \
-        auto k = gemm256w_kernel<SPEC, T>;                                                                   \
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);          \
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, gt);                                               \
-        return hip_rc(hipGetLastError());                                                                    \
-    }
-    switch (epi_spec_of(a)) {
-        VDA_CASE_W4(EPI_SPEC_OWN) VDA_CASE_W4(EPI_SPEC_OWN_GELU) VDA_CASE_W4(EPI_SPEC_F32_RES32)
-        default: return W4_NOT_HERE;
-    }
-#undef VDA_CASE_W4
-}
-
 template <typename T>
 int launch_t(const VdaGemmArgs& a, hipStream_t s) {
     GemmTiles gt{(a.M + 255) / 256, (a.N + 255) / 256};
@@ -539,12 +384,6 @@ int launch_t(const VdaGemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int launch_gemm256(const VdaGemmArgs& a, hipStream_t s) {
-    static const bool w4 = [] { const char* e = getenv("VDA_GEMM_W4"); return e && e[0] == '1'; }();
-    if ((w4 || a.tile_cfg == 4) && a.a_mode == VDA_A_LINEAR && !a.ab_pairs && !a.relu_in && (uint64_t)a.M * a.lda < (1ull << 31) &&
-        (uint64_t)a.N * a.K < (1ull << 31)) {
-        const int rc = a.ab_type == VDA_T_F16 ? launch_w4<f16>(a, s) : launch_w4<bf16>(a, s);
-        if (rc != W4_NOT_HERE) return rc;
-    }
     return a.ab_type == VDA_T_F16 ? launch_t<f16>(a, s) : launch_t<bf16>(a, s);
 }
 
