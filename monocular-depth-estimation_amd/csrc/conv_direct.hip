@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     char* wbuf = smem + HALO_BYTES;
+    char* up_tab = wbuf + 2 * W_BYTES;                       // UP: (HALO_H + HALO_W) x 16 bytes, see below
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
@@ -230,43 +231,42 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
         const int sh = half ? 2 : 3, iters = half ? (HALO_PX * 4 + 255) / 256 : HALO_ITERS;
         u32x4 res[HALO_ITERS];
         constexpr int G = TN >= 8 ? 2 : 4;                   // pieces whose four reads each are in flight together (registers)
-        // The positions and weights below do not depend on the channel slice.  Left alone the compiler computes them once,
-        // outside the slice loop, and keeps some hundred values live across the MFMA steps: make them depend on this call.
+        // What a piece needs besides its data -- the parked rows and columns it blends and their weights -- is separable and
+        // the same for every channel slice: it comes from the workgroup's tables (up_tab, built once), one entry per halo row
+        // and one per halo column.  Left alone the compiler would hoist the per-piece values out of the slice loop and keep
+        // some hundred of them live across the MFMA steps: make the piece index depend on this call.
         int t_id = tid;
         asm volatile("" : "+v"(t_id));
 #pragma unroll
         for (int g0 = 0; g0 < HALO_ITERS; g0 += G) {
-            u32x4 q[G][4];
-            float wy1[G], wx1[G];
-            bool okg[G];
+            u32x4 q[G][4], re[G], ce[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g0 + g >= iters) break;
+                const int hp = min(((g0 + g) * 256 + t_id) >> sh, HALO_PX - 1);     // (pad lanes blend the last pixel; not written)
+                const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+                re[g] = *reinterpret_cast<const u32x4*>(up_tab + hy * 16);
+                ce[g] = *reinterpret_cast<const u32x4*>(up_tab + (HALO_H + hx) * 16);
+            }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (g0 + g >= iters) break;
                 const int piece = (g0 + g) * 256 + t_id;
                 const int hp = piece >> sh, lo = piece & ((1 << sh) - 1), chunk = half ? lo : lo ^ (hp & 7);
-                const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-                const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-                okg[g] = hp < HALO_PX && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
-                // pieces outside the image (written as zeros) read inside the parked patch all the same
-                const float fy = up_sy * (float)min(max(iy, iy_lo), iy_hi), fx = up_sx * (float)min(max(ix, ix_lo), ix_hi);
-                const int y0 = (int)fy, x0 = (int)fx;
-                wy1[g] = fy - (float)y0;
-                wx1[g] = fx - (float)x0;
-                const int r0 = (y0 - ys0) * 32, r1 = (min(y0 + 1, src_h - 1) - ys0) * 32;
-                const int c0 = x0 - xs0, c1 = min(x0 + 1, src_w - 1) - xs0;
-                const int s0 = (chunk ^ (c0 & 7)) << 4, s1 = (chunk ^ (c1 & 7)) << 4;
-                q[g][0] = *reinterpret_cast<const u32x4*>(halo + (r0 + c0) * 128 + s0);
-                q[g][1] = *reinterpret_cast<const u32x4*>(halo + (r0 + c1) * 128 + s1);
-                q[g][2] = *reinterpret_cast<const u32x4*>(halo + (r1 + c0) * 128 + s0);
-                q[g][3] = *reinterpret_cast<const u32x4*>(halo + (r1 + c1) * 128 + s1);
+                const unsigned a0 = ce[g][0] ^ (unsigned)(chunk << 4), a1 = ce[g][1] ^ (unsigned)(chunk << 4);
+                q[g][0] = *reinterpret_cast<const u32x4*>(halo + (re[g][0] + a0));
+                q[g][1] = *reinterpret_cast<const u32x4*>(halo + (re[g][0] + a1));
+                q[g][2] = *reinterpret_cast<const u32x4*>(halo + (re[g][1] + a0));
+                q[g][3] = *reinterpret_cast<const u32x4*>(halo + (re[g][1] + a1));
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (g0 + g >= iters) break;
-                const float w00 = (1.f - wy1[g]) * (1.f - wx1[g]), w01 = (1.f - wy1[g]) * wx1[g];
-                const float w10 = wy1[g] * (1.f - wx1[g]), w11 = wy1[g] * wx1[g];
-                res[g0 + g] = blend4<T>(q[g], w00, w01, w10, w11);
-                if (!okg[g]) res[g0 + g] = u32x4{0u, 0u, 0u, 0u};
+                // (through named values: __builtin_bit_cast applied directly to a vector element reads element 0)
+                const unsigned uy0 = re[g][2], uy1 = re[g][3], ux0 = ce[g][2], ux1 = ce[g][3];
+                const float wy0 = __uint_as_float(uy0), wy1 = __uint_as_float(uy1);
+                const float wx0 = __uint_as_float(ux0), wx1 = __uint_as_float(ux1);
+                res[g0 + g] = blend4<T>(q[g], wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1);
             }
             __builtin_amdgcn_sched_barrier(0);               // keep the groups apart: only G x 4 reads are live at a time
         }
@@ -311,6 +311,33 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
     const int slices = (cin_eff + 63) / 64;
     const bool tail_half = (cin_eff & 63) == 32;
     const int steps = slices * SPC;
+    if (UP && parked) {
+        // Tables of the parked resampling: entry hy (10 halo rows) = {byte offset of parked row y0, of row y1, 1 - wy, wy},
+        // entry 10 + hx (34 halo columns) = {offset of parked column x0 incl. its chunk swizzle, of column x1, 1 - wx, wx};
+        // rows and columns outside the image get zero weights (the piece is then a zero), positions with ATen's arithmetic
+        // (src = scale * dst, i0 = (int)src).  A piece's four weights are products of one row and one column weight.
+        if (tid < HALO_H + HALO_W) {
+            const bool is_row = tid < HALO_H;
+            const int h = is_row ? tid : tid - HALO_H;
+            const int i_lo = is_row ? max(oy0 - 1, 0) : max(ox0 - 1, 0);
+            const int i_hi = is_row ? min(oy0 + PT_H, p.in_h - 1) : min(ox0 + PT_W, p.in_w - 1);
+            const int idx = (is_row ? oy0 : ox0) + h - 1, extent = is_row ? p.in_h : p.in_w, src_n = is_row ? src_h : src_w;
+            const float sc = is_row ? up_sy : up_sx;
+            const int s0 = (int)(sc * (float)i_lo);                                  // first parked row / column
+            const float f = sc * (float)min(max(idx, i_lo), i_hi);
+            const int i0 = (int)f, i1 = min(i0 + 1, src_n - 1);
+            const float w1 = f - (float)i0, w0 = 1.f - w1;
+            const bool ok = (unsigned)idx < (unsigned)extent;
+            const int e0 = i0 - s0, e1 = i1 - s0;
+            u32x4 e;
+            e[0] = is_row ? e0 * 32 * 128 : e0 * 128 + ((e0 & 7) << 4);
+            e[1] = is_row ? e1 * 32 * 128 : e1 * 128 + ((e1 & 7) << 4);
+            e[2] = __builtin_bit_cast(unsigned, ok ? w0 : 0.f);
+            e[3] = __builtin_bit_cast(unsigned, ok ? w1 : 0.f);
+            *reinterpret_cast<u32x4*>(up_tab + tid * 16) = e;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the first use lies behind the barrier that follows the parking)
+    }
     issue_w(0, 0);
     for (int s = 0; s < steps; ++s) {
         const int cc = s / SPC, tg = s - cc * SPC;
@@ -453,7 +480,7 @@ template <int TN, int TPS, bool RELU_IN, bool UP, int SPEC, typename T, bool PAI
 int launch_cfg(const VdaGemmArgs& a, hipStream_t s) {
     const int tiles_x = (a.out_w + PT_W - 1) / PT_W, tiles_y = (a.out_h + PT_H - 1) / PT_H;
     const int imgs = a.M / (a.out_h * a.out_w);
-    const int lds = HALO_BYTES + 2 * TPS * TN * 16 * 128;
+    const int lds = HALO_BYTES + 2 * TPS * TN * 16 * 128 + (UP ? (HALO_H + HALO_W) * 16 : 0);
     // The parked form of the resampling needs a patch's halo to come from at most 32 source columns and 11 source rows:
     // horizontal scale <= 0.9, vertical <= 1.  fp16 maps only: the bf16 blend converts every value and needs the registers
     // that form leaves to the four-tap loader.
