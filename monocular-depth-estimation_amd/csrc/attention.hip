@@ -37,10 +37,8 @@ template <> __device__ __forceinline__ f16x4 read_tr<f16>(const char* p) {      
     return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(p)));
 }
 
-// NW waves per workgroup (4 or 8) share the K/V tiles: 32 NW NQB queries per workgroup, starting at query q_first.
-template <int NQB, typename T, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_tok, int heads, int q_blocks,
-                                                          int q_first) {
+template <int NQB, typename T>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_tok, int heads, int q_blocks) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
@@ -56,7 +54,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const T* __restrict__ 
     const int frame = fh / heads, head = fh - frame * heads;
     const int D = heads * 64, ld = 3 * D;
     const T* base = qkv + (size_t)frame * n_tok * ld + head * 64;
-    const int q0 = q_first + qb * (32 * NW * NQB) + wave * (32 * NQB);
+    const int q0 = qb * (128 * NQB) + wave * (32 * NQB);
 
     // Q fragments (B operand of S^T = K Q^T): lane (r, h) holds Q[q0 + r][16 ks + 8 h + 0..7]
     v8 qf[NQB][4];
@@ -78,11 +76,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const T* __restrict__ 
         char* kb = smem + buf * 16384;
         char* vb = kb + 8192;
 #pragma unroll
-        for (int i = 0; i < 8 / NW; ++i) {                  // one instruction of the workgroup covers 8 NW rows
-            const int row = i * (8 * NW) + srow;
+        for (int i = 0; i < 2; ++i) {
+            const int row = i * 32 + srow;
             const size_t g = (size_t)min(kt * 64 + row, n_tok - 1) * ld;
-            glds16(kbase + g + ((sc ^ ((row >> 1) & 7)) << 3), kb + i * (1024 * NW) + wave * 1024);
-            glds16(vbase + g + ((sc ^ (((row >> 1) & 1) << 2)) << 3), vb + i * (1024 * NW) + wave * 1024);
+            glds16(kbase + g + ((sc ^ ((row >> 1) & 7)) << 3), kb + i * 4096 + wave * 1024);
+            glds16(vbase + g + ((sc ^ (((row >> 1) & 1) << 2)) << 3), vb + i * 4096 + wave * 1024);
         }
     };
 
@@ -593,11 +591,6 @@ extern "C" int vda_attention_pairs(const void* qkv2, void* out3, int frames, int
     return hip_rc(hipGetLastError());
 }
 
-static bool attn_wide() {        // VDA_ATTN_WIDE=0: four-wave workgroups only (A/B runs)
-    static const bool on = [] { const char* e = getenv("VDA_ATTN_WIDE"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
 extern "C" int vda_attention(const void* qkv, void* out, int frames, int n_tok, int heads, int dtype, void* stream) {
     if (!qkv || !out || frames <= 0 || n_tok <= 0 || heads <= 0) return VDA_EINVAL;
     if (dtype != VDA_T_BF16 && dtype != VDA_T_F16 && dtype != VDA_T_F32) return VDA_EINVAL;
@@ -615,23 +608,12 @@ extern "C" int vda_attention(const void* qkv, void* out, int frames, int n_tok, 
     if ((long)frames * heads * q_blocks > 0x7fffffffL) return VDA_ESHAPE;
     dim3 grid(frames * heads * q_blocks);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define VDA_ATTN(NQB, T, NW, BLOCKS, FIRST)                                                                                         \
-    hipLaunchKernelGGL((attn_kernel<NQB, T, NW>), dim3(frames * heads * (BLOCKS)), dim3(64 * NW), 0, st, reinterpret_cast<const T*>(qkv), \
-                       reinterpret_cast<T*>(out), n_tok, heads, BLOCKS, FIRST)
-    // 32 queries per wave: eight waves share a K/V tile (half the copy instructions per wave: the loop is bound by instruction
-    // issue) for the whole blocks of 256 queries; what is left goes to four-wave workgroups of 128 queries.  Only when the
-    // large workgroups fill the chip four times over (measured, 32 frames: 16 heads x 1370 tokens 310.5 -> 303.8 us, x 2443
-    // tokens 881 -> 864 us; 6 heads x 1370 tokens, 960 large workgroups, 128 -> 131 us).  Same arithmetic per query: same bits.
-    const bool wide = nqb == 1 && attn_wide() && (long)frames * heads * (n_tok / 256) >= 2048;
-    const int big = wide ? n_tok / 256 : 0, rest = n_tok - 256 * big;
-    const int small = (rest + 128 * nqb - 1) / (128 * nqb);
-    (void)grid;
+#define VDA_ATTN(NQB, T) hipLaunchKernelGGL((attn_kernel<NQB, T>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(qkv), \
+                                            reinterpret_cast<T*>(out), n_tok, heads, q_blocks)
     if (dtype == VDA_T_F16) {
-        if (big) VDA_ATTN(1, f16, 8, big, 0);
-        if (small) { if (nqb == 2) VDA_ATTN(2, f16, 4, small, 256 * big); else VDA_ATTN(1, f16, 4, small, 256 * big); }
+        if (nqb == 2) VDA_ATTN(2, f16); else VDA_ATTN(1, f16);
     } else {
-        if (big) VDA_ATTN(1, bf16, 8, big, 0);
-        if (small) { if (nqb == 2) VDA_ATTN(2, bf16, 4, small, 256 * big); else VDA_ATTN(1, bf16, 4, small, 256 * big); }
+        if (nqb == 2) VDA_ATTN(2, bf16); else VDA_ATTN(1, bf16);
     }
 #undef VDA_ATTN
     return hip_rc(hipGetLastError());

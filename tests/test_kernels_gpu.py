@@ -374,28 +374,6 @@ def test_attention(frames, n_tok, heads, dt):
     close(out, want, ATTN_TOL[dt], "attention")       # probabilities are rounded to the operand type before the second product
 
 
-@pytest.mark.parametrize("dt", ATTN_TYPES)
-@pytest.mark.parametrize("n_tok", [1370, 600])
-def test_attention_with_eight_wave_workgroups(n_tok, dt):
-    """Calls whose grid fills the chip several times over (frames x heads x whole blocks of 256 queries >= 2048) give the blocks
-    of 256 queries to eight-wave workgroups and the rest to four-wave ones: against fp32 torch, and bit for bit against the
-    same frames computed in calls too small for that (every query's arithmetic is the same in both)."""
-    heads = 16
-    frames = 2048 // (heads * (n_tok // 256)) + 1
-    D = heads * 64
-    qkv = rnd((frames, n_tok, 3 * D), 7, 0.7, dt)
-    out = torch.full((frames, n_tok, D), float("nan"), dtype=dt, device=DEV)
-    hip.attention(qkv, out, frames, n_tok, heads)
-    q, k, v = qkv[:2].float().reshape(2, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
-    want = (softmax2(q @ k.transpose(-1, -2)) @ v).transpose(1, 2).reshape(2, n_tok, D)
-    close(out[:2], want, ATTN_TOL[dt], "attention, eight-wave workgroups")
-    narrow = torch.full_like(out, float("nan"))
-    for f in range(0, frames, 4):
-        n = min(4, frames - f)
-        hip.attention(qkv[f:f + n], narrow[f:f + n], n, n_tok, heads)
-    assert torch.equal(out, narrow)
-
-
 @pytest.mark.parametrize("n_tok", [200, 4200])       # 32 and 64 queries per wave
 @pytest.mark.parametrize("dt", ATTN_TYPES)
 def test_attention_sharp_softmax_rescale(n_tok, dt):
