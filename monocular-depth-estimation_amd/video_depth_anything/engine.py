@@ -1,14 +1,16 @@
 """The per-window forward pass as a sequence of libvda_hip kernel launches on the current HIP stream.
 
 Layouts in HBM (T frames, hp x wp patches, N = hp*wp + 1 tokens, D embed dim):
-  * encoder residual stream  fp32 [frame][token][D]; every GEMM operand bf16; accumulation fp32;
-  * head feature maps        bf16 channels-last [frame][y][x][C] (C padded to a multiple of 64), so a 1x1 convolution or
+  * encoder residual stream  fp32 [frame][token][D]; every GEMM operand 16-bit (bf16, or fp16 on request); accumulation fp32;
+  * head feature maps        fp16 channels-last [frame][y][x][C] (C padded to a multiple of 64), so a 1x1 convolution or
                              Linear is a plain GEMM on the same buffer and the temporal modules need no transposes;
   * temporal hidden state    fp32 [frame][position][C];
   * depth                    fp32 [frame][H][W].
 In the fp32 storage mode (``PackedWeights(precision="fp32")``, the reference's ``fp32=True``) every activation above is
-fp32 instead of 16-bit; each GEMM operand is split into bf16 [hi | lo | hi] triples right before its product (weights are
-packed [hi | hi | lo]), so the same MFMA kernels accumulate the three-term hi/lo product over K' = 3K.
+fp32 instead of 16-bit; what a product reads are the operand's IEEE-half pieces hi = f16(s v), lo = f16(s v - hi) (weights
+are packed the same way), written by the kernel that produced the values where there is one and by ``vda_split3`` otherwise,
+and the kernels accumulate hi*hi + lo*hi + hi*lo (``packing.PIECES_PAIRS``: from one copy of each piece; ``PIECES_TRIPLE``:
+as a plain product over K' = 3K).
 torch is used for allocation (caching allocator = workspace reuse) and the stream only.
 """
 import os
@@ -75,7 +77,7 @@ class Engine:
 
     # ---- small wrappers -------------------------------------------------------------------------------------------
     def operand(self, a, relu=False, act=None):
-        """The MFMA operand of activation matrix ``a`` [rows, K]: itself, or its bf16 [hi | lo | hi] split in fp32 mode
+        """The MFMA operand of activation matrix ``a`` [rows, K]: itself, or its hi/lo pieces (``self.layout``) in fp32 mode
         (``act``: an activation the split applies first; GEGLU halves the width)."""
         if isinstance(a, Pieces):
             assert act is None and not relu

@@ -131,8 +131,8 @@ PRECISIONS = {"half": (False, False, False), "fp32": (True, True, True), "enc32"
 
 
 class PackedWeights:
-    """Device-resident kernel-layout weights of one model.  ``precision`` "fp32" packs every matrix as 16-bit hi/lo triples
-    (``SplitWeight``) for the fp32 storage mode (``head_dtype`` is then ignored); see PRECISIONS for the mixed forms."""
+    """Device-resident kernel-layout weights of one model.  ``precision`` "fp32" packs every matrix as 16-bit hi/lo pieces
+    (``SplitWeight``, in ``layout``) for the fp32 storage mode (``head_dtype`` is then ignored); see PRECISIONS for the mixed forms."""
 
     def __init__(self, sd, encoder, features, out_channels, device, head_dtype=torch.float16, precision="half", layout=None,
                  encoder_dtype=None):
