@@ -1,6 +1,7 @@
 """Error and speed of every precision form (packing.PRECISIONS: the two modes of the model and the mixed measurement
 forms) on depth maps with clamped pixels: the ViT-S goldens of the reference (G4b forward, G5b video), ViT-L 1x8x3x518x518
-against the oracle executed on the device, and the ViT-L 32-frame window rate.    python tools/precision_table.py [--no-vitl]"""
+against the oracle executed on the device, and the ViT-L 32-frame window rate.
+    python tools/precision_table.py [--no-vitl] [forms ...]      (VDA_ENCODER_DTYPE=fp16: the 16-bit forms with IEEE-half encoder operands)"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +11,7 @@ from video_depth_anything import spec
 from video_depth_anything.packing import PRECISIONS
 from video_depth_anything.video_depth import VideoDepthAnything
 
-MODES = [m for m in ("half", "tail32", "head32", "enc32", "fp32") if m in PRECISIONS]
+MODES = [m for m in ("half", "tail32", "head32", "enc32", "fp32") if m in PRECISIONS and (m in sys.argv or not any(a in PRECISIONS for a in sys.argv))]
 
 
 def line(name, got, want):
