@@ -203,7 +203,10 @@ class Engine:
     def folds_layernorms(self):
         """Whether the encoder blocks' LayerNorms are folded into qkv / fc1 on this engine."""
         D = self.w.D
-        return (D < 1024 if self.fold_layernorm is None else bool(self.fold_layernorm)) and not self.split_enc and D % 64 == 0
+        # (by default not with IEEE-half operands: the folded form stores the UN-normalised residual rows in the operand type,
+        # and a residual value beyond 65504 would saturate there without notice; bf16 has fp32's range)
+        auto = D < 1024 and self.edt != torch.float16
+        return (auto if self.fold_layernorm is None else bool(self.fold_layernorm)) and not self.split_enc and D % 64 == 0
 
     def encoder_frames(self, x, f0, f1, H, W, taps):
         """Frames f0..f1-1 through the encoder on the current stream; writes their rows of the tap buffers."""
