@@ -93,7 +93,7 @@ typedef struct VdaGemmArgs {
     int in_h, in_w, cin, out_h, out_w, stride;   /* CONV3 geometry; cin % 64 == 0, M = imgs*out_h*out_w */
     int ct_h, ct_w, ct_k, ct_c;                  /* EPI_CONVT geometry                                   */
     int tile_cfg;         /* 0 = the library picks the kernel; 1..3 force one where the call allows it (tuning and tests):
-                             1 = 128x128 tile / 4 waves, 2 = 256x256 tile / 8 waves, 4-phase pipelined, 3 = direct 3x3
+                             1 = 128x128 tile / 4 waves, 2 = 256x256 tile / 8 waves, software-pipelined, 3 = direct 3x3
                              convolution (stride 1, N = 32, 64 or a multiple of 128, no gamma); other values are VDA_EINVAL */
     int up_h, up_w;       /* CONV3 only; 0 = off.  Otherwise `a` is the NHWC map [img][up_h][up_w][cin] and the convolution
                              input is its bilinear resampling (align_corners=True, arithmetic of vda_bilinear_nhwc) to
