@@ -216,6 +216,35 @@ def test_packed_weights_fold_the_encoder_layernorms_into_qkv_and_fc1():
                                           precision="fp32").blocks[0]           # the fp32 mode keeps the separate pass
 
 
+def test_packed_weights_take_the_encoder_operand_type_and_both_piece_layouts():
+    """``encoder_dtype`` selects the 16-bit type of every encoder matrix (and nothing else); the fp32 mode's weights are
+    hi/lo pieces whose sum reproduces scale * w to 2^-21 in either layout."""
+    from video_depth_anything.packing import PIECES_PAIRS, PIECES_TRIPLE, PackedWeights, SplitWeight
+    cfg = spec.MODEL_CONFIGS["vits"]
+    sd = {k: torch.from_numpy(v) for k, v in spec.synth_state_dict(**cfg, seed=1).items()}
+    args = (sd, cfg["encoder"], cfg["features"], cfg["out_channels"], torch.device("cpu"))
+    bf, hf = PackedWeights(*args), PackedWeights(*args, encoder_dtype=torch.float16)
+    assert bf.encoder_dtype == torch.bfloat16 and hf.encoder_dtype == torch.float16
+    for key in ("wqkv", "wproj", "wfc1", "wfc2", "wqkv_ln", "wfc1_ln"):
+        assert bf.blocks[3][key].dtype == torch.bfloat16 and hf.blocks[3][key].dtype == torch.float16
+    assert hf.patch_w.dtype == torch.float16 and hf.proj_w[0].dtype == bf.proj_w[0].dtype == torch.float16      # the head's type is its own
+    with pytest.raises(ValueError):
+        PackedWeights(*args, encoder_dtype=torch.float32)
+    assert PackedWeights(*args, precision="fp32", encoder_dtype=torch.float16).encoder_dtype == torch.float32  # pieces instead
+    w = torch.randn(96, 128, generator=torch.Generator().manual_seed(3)) * 0.05
+    for layout in (PIECES_TRIPLE, PIECES_PAIRS):
+        sw = SplitWeight(w, layout=layout)
+        t = sw.t.double()
+        if layout == PIECES_PAIRS:
+            blocks = t.reshape(96, 4, 2, 32)
+            hi, lo = blocks[:, :, 0].reshape(96, 128), blocks[:, :, 1].reshape(96, 128)
+        else:
+            hi, lo = t[:, :128], t[:, 256:]
+            assert torch.equal(t[:, :128], t[:, 128:256])
+        assert ((hi + lo) / sw.scale - w.double()).abs().max() <= 2.0 ** -21 * w.abs().max()
+        assert 1024 <= float((w * sw.scale).abs().max()) < 2048
+
+
 def test_gemm_argument_struct_matches_the_header():
     """hip.GemmArgs mirrors VdaGemmArgs field by field: compile the header and compare size and the offsets of the last fields."""
     import ctypes
