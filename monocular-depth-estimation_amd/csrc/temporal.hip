@@ -10,6 +10,20 @@
 
 namespace {
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2(f16x2 a, f16x2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+__device__ __forceinline__ float dot2(bf16x2 a, bf16x2 b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
+// c + w * (one half of the packed fp16 pair h2), the half converted inside the instruction
+template <int HI>
+__device__ __forceinline__ float mix_fma_f16(unsigned h2, float w, float c) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(w), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(w), "v"(c));
+    return r;
+}
+
 template <int HD, typename T16>
 __global__ __launch_bounds__(64) void temporal_attn_kernel(const T16* __restrict__ qkv, T16* __restrict__ out, int T,
                                                            int hw, int heads, float scale_log2e) {
@@ -49,14 +63,25 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const T16* __restrict
             *reinterpret_cast<piece_t*>(&vs[j * HD + c]) = vp[it];
         }
     }
-    float q[HH];
+    // 16-bit types: the dot products run on the packed two-element dot instruction (fp32 accumulation, no conversions) on the
+    // rows as stored; the scale is applied to the sums.  fp32: plain fused multiply-adds on pre-scaled q.
+    constexpr bool PACKED = sizeof(T16) == 2;
+    typedef typename std::conditional<PACKED, T16, _Float16>::type P16;
+    typedef P16 pair_t __attribute__((ext_vector_type(2)));
+    float q[PACKED ? 1 : HH];
+    pair_t qp[PACKED ? HH / 2 : 1];
     {
         const T16* qrow = base + (size_t)min(t, T - 1) * fstride + half * HH;
 #pragma unroll
         for (int i = 0; i < V4; ++i) {
             const v4_t v = *reinterpret_cast<const v4_t*>(qrow + 4 * i);
+            if constexpr (PACKED) {
+                qp[2 * i] = pair_t{(P16)v[0], (P16)v[1]};
+                qp[2 * i + 1] = pair_t{(P16)v[2], (P16)v[3]};
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[4 * i + k] = (float)v[k] * scale_log2e;
+                for (int k = 0; k < 4; ++k) q[4 * i + k] = (float)v[k] * scale_log2e;
+            }
         }
     }
     __syncthreads();
@@ -69,10 +94,16 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const T16* __restrict
 #pragma unroll
             for (int i = 0; i < V4; ++i) {
                 const v4_t k4 = *reinterpret_cast<const v4_t*>(&ks[j * HD + half * HH + 4 * i]);
+                if constexpr (PACKED) {
+                    acc = dot2(qp[2 * i], pair_t{(P16)k4[0], (P16)k4[1]}, acc);
+                    acc = dot2(qp[2 * i + 1], pair_t{(P16)k4[2], (P16)k4[3]}, acc);
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc = fmaf(q[4 * i + k], (float)k4[k], acc);
+                    for (int k = 0; k < 4; ++k) acc = fmaf(q[4 * i + k], (float)k4[k], acc);
+                }
             }
             acc += __shfl_xor(acc, 32);
+            if constexpr (PACKED) acc *= scale_log2e;
         } else {
             acc = -INFINITY;
         }
@@ -96,8 +127,16 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const T16* __restrict
 #pragma unroll
             for (int i = 0; i < V4; ++i) {
                 const v4_t v4 = *reinterpret_cast<const v4_t*>(&vs[j * HD + half * HH + 4 * i]);
+                if constexpr (std::is_same<T16, f16>::value) {       // mixed-precision FMA: the half is converted inside the instruction
+                    const u32x2 b = __builtin_bit_cast(u32x2, v4);
+                    o[4 * i] = mix_fma_f16<0>(b[0], s[j], o[4 * i]);
+                    o[4 * i + 1] = mix_fma_f16<1>(b[0], s[j], o[4 * i + 1]);
+                    o[4 * i + 2] = mix_fma_f16<0>(b[1], s[j], o[4 * i + 2]);
+                    o[4 * i + 3] = mix_fma_f16<1>(b[1], s[j], o[4 * i + 3]);
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[4 * i + k] = fmaf(s[j], (float)v4[k], o[4 * i + k]);
+                    for (int k = 0; k < 4; ++k) o[4 * i + k] = fmaf(s[j], (float)v4[k], o[4 * i + k]);
+                }
             }
         }
     }
