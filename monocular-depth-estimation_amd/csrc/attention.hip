@@ -13,9 +13,6 @@
 namespace {
 
 
-// byte offset of element (key row, 16-bit column col) in the V tile: 128-byte rows, the two 64-byte halves of a row
-// swapped on rows 2,3 (mod 4) so the 4 rows of a transposed 4x16 block read fall on distinct banks
-__device__ __forceinline__ int v_off(int row, int col) { return row * 128 + ((col * 2) ^ (((row >> 1) & 1) << 6)); }
 
 // Scores are base-2 logarithms: the caller folds log2(e) / sqrt(64) into q, so a probability is exp2(score - maximum) and
 // v_exp_f32 needs no multiply in front of it.
@@ -28,15 +25,6 @@ constexpr float DEFER = 6.0f;
 // the two 16-bit operand types of the 32x32x16 products and of the transposed 4 x 16 block read
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-template <typename T> __device__ __forceinline__ typename Vec<T>::v4 read_tr(const char* p);
-template <> __device__ __forceinline__ bf16x4 read_tr<bf16>(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(p));
-}
-typedef short i16x4 __attribute__((ext_vector_type(4)));
-template <> __device__ __forceinline__ f16x4 read_tr<f16>(const char* p) {      // (the builtin's own half type is not _Float16)
-    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(p)));
-}
-
 template <int NQB, typename T>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_tok, int heads, int q_blocks) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];

@@ -136,4 +136,18 @@ __device__ __forceinline__ void store_pieces(T* row, int c, int Cw, int form, ty
     }
 }
 
+// ---- transposed operand reads of a row-major [key][64 values] tile of 16-bit values in LDS (the V operand of attention) ----------
+// byte offset of element (key row, 16-bit column col) in the tile: 128-byte rows, the two 64-byte halves of a row swapped on
+// rows 2,3 (mod 4) so the 4 rows of a transposed 4x16 block read fall on distinct banks
+__device__ __forceinline__ int v_off(int row, int col) { return row * 128 + ((col * 2) ^ (((row >> 1) & 1) << 6)); }
+// ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies the address of row q, columns 4p..4p+3; every lane must be active
+template <typename T> __device__ __forceinline__ typename Vec<T>::v4 read_tr(const char* p);
+template <> __device__ __forceinline__ bf16x4 read_tr<bf16>(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(p));
+}
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+template <> __device__ __forceinline__ f16x4 read_tr<f16>(const char* p) {      // (the builtin's own half type is not _Float16)
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(p)));
+}
+
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }

@@ -584,7 +584,9 @@ def test_patch_embed_front_end():
 
 
 @pytest.mark.parametrize("dt", STORAGE)
-@pytest.mark.parametrize("B,T,hw,heads,hd", [(1, 32, 12, 8, 24), (2, 5, 7, 8, 48), (1, 32, 9, 8, 8), (1, 32, 10, 8, 128), (1, 4, 6, 8, 32), (1, 1, 5, 8, 8)])
+@pytest.mark.parametrize("B,T,hw,heads,hd", [(1, 32, 12, 8, 24), (2, 5, 7, 8, 48), (1, 32, 9, 8, 8), (1, 32, 10, 8, 128), (1, 4, 6, 8, 32), (1, 1, 5, 8, 8),
+                                             (2, 7, 5, 8, 128), (1, 32, 3, 4, 64), (1, 13, 4, 2, 96), (1, 1, 3, 8, 32), (1, 32, 50, 8, 32),
+                                             (1, 6, 4, 3, 32), (1, 32, 5, 6, 8), (2, 9, 3, 16, 16)])
 def test_temporal_attention(B, T, hw, heads, hd, dt):
     C = heads * hd
     qkv = rnd((B * T * hw, 3 * C), 1, 1.0, dt)
