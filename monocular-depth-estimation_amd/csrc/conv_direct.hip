@@ -9,8 +9,8 @@
 // weights are streamed per tap.
 //
 // 4 waves; wave w owns patch rows 2w, 2w+1 = four 16-pixel MFMA row tiles x all N channels (4 x N/16 accumulator tiles).
-// LDS: one halo slice (340 pixels x 128 B) + two weight buffers (one step = TPS taps x N rows x 128 B): <= 78 KiB, so two
-// workgroups share a CU and one computes while the other waits for its next halo slice.
+// LDS: one halo slice (340 pixels x 128 B) + two weight buffers (one step = TPS taps x N rows x 128 B): <= 78 KiB for the
+// (N, TPS) pairs the launcher picks, so two workgroups share a CU and one computes while the other waits for its next halo slice.
 // Step loop (a step = TPS taps of one channel slice):  [first step of a slice: issue the halo copies]  issue the weight
 // copies of the next step; wait until everything but those has landed (counted vmcnt; copies retire in issue order);
 // barrier; MFMAs; barrier (the buffers may be refilled).
@@ -351,9 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
         }
         if (s + 1 < steps) {
             issue_w(s + 1, (s + 1) & 1);
-            if (W_ITERS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if (W_ITERS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_ITERS) : "memory");      // everything but the copies just issued
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -494,7 +492,10 @@ int launch_cfg(const VdaGemmArgs& a, hipStream_t s) {
 template <bool RELU_IN, bool UP, int SPEC, typename T, bool PAIRS = false>
 int launch_r(const VdaGemmArgs& a, hipStream_t s) {
     if (a.N % 128 == 0) return launch_cfg<8, 1, RELU_IN, UP, SPEC, T, PAIRS>(a, s);
-    if (a.N == 64) return launch_cfg<4, 3, RELU_IN, UP, SPEC, T, PAIRS>(a, s);
+    // Taps per step: as many as leave room for two workgroups per CU (halo 44 KiB + two weight buffers <= 80 KiB).  64 channels
+    // with three taps per step (92 KiB) ran one workgroup per CU: +2.4 % on the ViT-S window for one tap per step.  32 channels
+    // with one tap per step (three workgroups per CU) is slower than three taps and two workgroups (1773 against 1632 us).
+    if (a.N == 64) return launch_cfg<4, 1, RELU_IN, UP, SPEC, T, PAIRS>(a, s);
     return launch_cfg<2, 3, RELU_IN, UP, SPEC, T, PAIRS>(a, s);
 }
 
