@@ -110,7 +110,9 @@ __device__ __forceinline__ u32x4 blend2<bf16>(const u32x4& a, const u32x4& b, fl
 // PAIRS (VdaGemmArgs.ab_pairs): a 64-column channel slice is [hi 32 | lo 32] of 32 operand channels, in the map and in the
 // weights; a tap multiplies W_lo A_hi + W_hi A_lo + W_hi A_hi from one halo slice and one read of each fragment.
 template <int TN, int TPS, bool RELU_IN, bool UP, int SPEC, typename T, bool PAIRS = false>
-__global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs pa, const int tiles_x, const int tiles_y, const int parked) {
+__global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs pa, const int tiles_x, const int tiles_y, const int parked_arg) {
+    // (the parked form of the resampling exists for fp16 maps only; the launcher asks for it for no other type)
+    const bool parked = __is_same(T, f16) && parked_arg;
     const VdaGemmArgs p = epi_spec_args<SPEC, T>(pa);          // the epilogue's choices as constants (EPI_SPEC_*)
     typedef typename Vec<T>::v8 frag_t;
     constexpr int N = TN * 16;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
         // A half slice (only 32 of the slice's 64 channels are used) has four pieces per halo pixel instead of eight.
         const int sh = half ? 2 : 3, iters = half ? (HALO_PX * 4 + 255) / 256 : HALO_ITERS;
         u32x4 res[HALO_ITERS];
-        constexpr int G = TN >= 8 ? 2 : 4;                   // pieces whose four reads each are in flight together (registers)
+        constexpr int G = TN >= 8 ? 1 : 4;                   // pieces whose four reads each are in flight together (registers)
         // What a piece needs besides its data -- the parked rows and columns it blends and their weights -- is separable and
         // the same for every channel slice: it comes from the workgroup's tables (up_tab, built once), one entry per halo row
         // and one per halo column.  Left alone the compiler would hoist the per-piece values out of the slice loop and keep
@@ -239,34 +241,39 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
         asm volatile("" : "+v"(t_id));
 #pragma unroll
         for (int g0 = 0; g0 < HALO_ITERS; g0 += G) {
+            // (guards, not breaks: a loop with an early exit is not unrolled into straight code, its index into `res` stays a
+            // run-time value and the array lands in scratch memory, one memory round trip per piece on the way back)
             u32x4 q[G][4], re[G], ce[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if (g0 + g >= iters) break;
-                const int hp = min(((g0 + g) * 256 + t_id) >> sh, HALO_PX - 1);     // (pad lanes blend the last pixel; not written)
-                const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-                re[g] = *reinterpret_cast<const u32x4*>(up_tab + hy * 16);
-                ce[g] = *reinterpret_cast<const u32x4*>(up_tab + (HALO_H + hx) * 16);
+                if (g0 + g < HALO_ITERS && g0 + g < iters) {
+                    const int hp = min(((g0 + g) * 256 + t_id) >> sh, HALO_PX - 1);     // (pad lanes blend the last pixel; not written)
+                    const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+                    re[g] = *reinterpret_cast<const u32x4*>(up_tab + hy * 16);
+                    ce[g] = *reinterpret_cast<const u32x4*>(up_tab + (HALO_H + hx) * 16);
+                }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if (g0 + g >= iters) break;
-                const int piece = (g0 + g) * 256 + t_id;
-                const int hp = piece >> sh, lo = piece & ((1 << sh) - 1), chunk = half ? lo : lo ^ (hp & 7);
-                const unsigned a0 = ce[g][0] ^ (unsigned)(chunk << 4), a1 = ce[g][1] ^ (unsigned)(chunk << 4);
-                q[g][0] = *reinterpret_cast<const u32x4*>(halo + (re[g][0] + a0));
-                q[g][1] = *reinterpret_cast<const u32x4*>(halo + (re[g][0] + a1));
-                q[g][2] = *reinterpret_cast<const u32x4*>(halo + (re[g][1] + a0));
-                q[g][3] = *reinterpret_cast<const u32x4*>(halo + (re[g][1] + a1));
+                if (g0 + g < HALO_ITERS && g0 + g < iters) {
+                    const int piece = (g0 + g) * 256 + t_id;
+                    const int hp = piece >> sh, lo = piece & ((1 << sh) - 1), chunk = half ? lo : lo ^ (hp & 7);
+                    const unsigned a0 = ce[g][0] ^ (unsigned)(chunk << 4), a1 = ce[g][1] ^ (unsigned)(chunk << 4);
+                    q[g][0] = *reinterpret_cast<const u32x4*>(halo + (re[g][0] + a0));
+                    q[g][1] = *reinterpret_cast<const u32x4*>(halo + (re[g][0] + a1));
+                    q[g][2] = *reinterpret_cast<const u32x4*>(halo + (re[g][1] + a0));
+                    q[g][3] = *reinterpret_cast<const u32x4*>(halo + (re[g][1] + a1));
+                }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if (g0 + g >= iters) break;
-                // (through named values: __builtin_bit_cast applied directly to a vector element reads element 0)
-                const unsigned uy0 = re[g][2], uy1 = re[g][3], ux0 = ce[g][2], ux1 = ce[g][3];
-                const float wy0 = __uint_as_float(uy0), wy1 = __uint_as_float(uy1);
-                const float wx0 = __uint_as_float(ux0), wx1 = __uint_as_float(ux1);
-                res[g0 + g] = blend4<T>(q[g], wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1);
+                if (g0 + g < HALO_ITERS && g0 + g < iters) {
+                    // (through named values: __builtin_bit_cast applied directly to a vector element reads element 0)
+                    const unsigned uy0 = re[g][2], uy1 = re[g][3], ux0 = ce[g][2], ux1 = ce[g][3];
+                    const float wy0 = __uint_as_float(uy0), wy1 = __uint_as_float(uy1);
+                    const float wx0 = __uint_as_float(ux0), wx1 = __uint_as_float(ux1);
+                    res[g0 + g] = blend4<T>(q[g], wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);               // keep the groups apart: only G x 4 reads are live at a time
         }
@@ -275,10 +282,11 @@ __global__ __launch_bounds__(256, 2) void conv3_direct_kernel(const VdaGemmArgs 
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int it = 0; it < HALO_ITERS; ++it) {
-            if (it >= iters) break;
-            const int piece = it * 256 + t_id;
-            const int hp = piece >> sh, lo = piece & ((1 << sh) - 1), chunk = half ? lo : lo ^ (hp & 7);
-            if (hp < HALO_PX) *reinterpret_cast<u32x4*>(halo + hp * 128 + ((chunk ^ (hp & 7)) << 4)) = res[it];
+            if (it < iters) {
+                const int piece = it * 256 + t_id;
+                const int hp = piece >> sh, lo = piece & ((1 << sh) - 1), chunk = half ? lo : lo ^ (hp & 7);
+                if (hp < HALO_PX) *reinterpret_cast<u32x4*>(halo + hp * 128 + ((chunk ^ (hp & 7)) << 4)) = res[it];
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
