@@ -124,6 +124,37 @@ def test_device_code_has_no_packed_fp32_instruction_that_reads_a_high_register_f
     assert packed > 1000        # the disassembly did see the GEMM epilogues' packed arithmetic
 
 
+def test_hot_kernels_use_no_scratch_memory(tmp_path):
+    """A kernel's private segment is memory: a value the compiler keeps there (a register spill, or an array whose index it
+    could not resolve at compile time) costs a memory round trip where it is read back.  The fused-upsampling convolutions
+    once kept their blended halo pieces there (1.6 against 1.2 ms).  Only the epilogues that serve no hot call may use one:
+    the general (unspecialised) forms, and the 256x256 kernel's edge-tile fallback of the fp32 residual form."""
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(readelf) and os.path.exists(objdump)):
+        pytest.skip("llvm-readelf / llvm-objdump of the ROCm toolchain are not installed")
+    import shutil
+    lib = shutil.copy(hip.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", os.path.basename(lib)], cwd=tmp_path, capture_output=True, check=True)
+    objects = sorted(p for p in os.listdir(tmp_path) if p.endswith("gfx950"))
+    seen, bad = 0, []
+    for o in objects:
+        notes = subprocess.run([readelf, "--notes", o], cwd=tmp_path, capture_output=True, text=True, check=True).stdout
+        for blk in re.split(r"\n  - ", notes):
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            size = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+            if not name or not size:
+                continue
+            seen += 1
+            n = name.group(1)
+            general = re.search(r"gemm_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi0E", n) or re.search(r"gemm256_kernelILi\d+ELb\dELi0E", n)
+            edge_fallback = re.search(r"gemm256_kernelILi0ELb0ELi(3|14)E", n)
+            if int(size.group(1)) > 0 and not general and not edge_fallback:
+                bad.append((n, int(size.group(1))))
+    assert seen > 300, seen
+    assert not bad, bad[:5]
+
+
 def test_wrappers_refuse_extents_beyond_the_tensor_storage():
     """Every kernel wrapper checks its shape arguments against the memory behind its tensors before it launches (a kernel that
     runs past a buffer faults the GPU).  The check counts from a view's first element to the end of its storage."""
