@@ -66,6 +66,7 @@ class Engine:
         self.side_streams = []
         self.head_streams = 2         # 2: parts of the head run on the first side stream beside the rest (see head())
         self.kept = None              # encoder outputs of the last keyed forward() (see forward)
+        self.slot_index = {}          # device index tensors of the carried slots, by slot list (see encoder)
         # 16-bit mode: the encoder blocks' LayerNorms can be folded into the qkv / fc1 products (see encoder_frames).
         # None = where it pays: at ViT-S width (+1.2 % on the window).  At ViT-L width the separate pass already hides under
         # the other stream's matrix-bound kernels (two streams: no gain; one stream +0.7 %) while the residual products,
@@ -170,7 +171,11 @@ class Engine:
         if carried is not None:
             prev, slots = carried
             first = len(slots)
-            idx = torch.tensor(slots, dtype=torch.int64, device=dev)
+            # (kept per slot list: building a device tensor from a Python list is a blocking copy, which made the host wait
+            # for the device once per window; a video's windows carry the same slots over)
+            idx = self.slot_index.get(tuple(slots))
+            if idx is None:
+                idx = self.slot_index[tuple(slots)] = torch.tensor(slots, dtype=torch.int64, device=dev)
             for t, p in zip(taps, prev):
                 torch.index_select(p.view(-1, hw * p.shape[1]), 0, idx, out=t[:first * hw].view(first, hw * t.shape[1]))
         if first == frames:
