@@ -169,7 +169,7 @@ class HostSink:
         k = min(len(maps), self.n - start)
         if k <= 0:
             return
-        block = torch.stack(list(maps[:k]), 0)
+        block = maps[:k] if torch.is_tensor(maps) else torch.stack(list(maps[:k]), 0)      # a contiguous run of maps, or a list
         self.have[start:start + k] = True
         if self.stream is None:
             self.out[start:start + k] = block.numpy()
@@ -217,7 +217,7 @@ class DeviceSink:
     def push(self, start, maps):
         k = min(len(maps), self.n - start)
         if k > 0:
-            self.out[start:start + k] = torch.stack(list(maps[:k]), 0)
+            self.out[start:start + k] = maps[:k] if torch.is_tensor(maps) else torch.stack(list(maps[:k]), 0)
             self.have[start:start + k] = True
 
     def close(self):
@@ -371,17 +371,21 @@ def _run_windows(model, sink, fwd, keyed, src, frame_ids, runs, stitched, shard_
                         if own:
                             pd = pds[b]
                             start, slot, cnt = runs[w]
-                            final = []
-                            for i in range(cnt):
-                                s = slot + i
-                                if w > 0 and s < OVERLAP:          # slots 2..9: cross-fade onto the previous window's tail
-                                    final.append(al.blend(pd[s], prev_tail[s - (OVERLAP - INTERP_LEN)], s - (OVERLAP - INTERP_LEN)))
-                                else:
-                                    final.append(al.apply(pd[s], w))
-                            sink.push(start, final)
+                            if w == 0:                             # the video's reference window: unchanged
+                                sink.push(start, pd[slot:slot + cnt])
+                            elif cnt > 0:
+                                final = torch.empty((cnt, h0, w0), dtype=torch.float32, device=dev)
+                                i = 0
+                                while i < cnt and slot + i < OVERLAP:      # slots 2..9: cross-fade onto the previous window's tail
+                                    q = slot + i - (OVERLAP - INTERP_LEN)
+                                    al.blend(pd[slot + i], prev_tail[q], q, out=final[i])
+                                    i += 1
+                                if i < cnt:                        # every other slot: scale and shift, one launch for the run
+                                    al.apply(pd[slot + i:slot + cnt], w, out=final[i:])
+                                sink.push(start, final)
                         # the aligned tail of window w is read by the owner of window w + 1
                         if w + 1 < n_win and owner_of[w + 1] == rank:
-                            prev_tail = [al.apply(tail[i], w) for i in range(INTERP_LEN)]
+                            prev_tail = al.apply(tail if torch.is_tensor(tail) else torch.stack(list(tail), 0), w)
             pending = cur
 
     if keyed:

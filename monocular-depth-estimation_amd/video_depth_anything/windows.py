@@ -122,18 +122,23 @@ class Aligner:
         hip.solve_scale_shift(self.sums, self.ss)
         self.ref1 = self.apply(d12, w)
 
-    def apply(self, x, w, pre=None, w_pre=0.0, w_post=1.0):
-        """max(s*x + t, 0) with the current window's fit (window 0 is the reference frame of the video: unchanged)."""
+    def apply(self, x, w, pre=None, w_pre=0.0, w_post=1.0, out=None):
+        """max(s*x + t, 0) with the current window's fit (window 0 is the reference frame of the video: unchanged).  ``x`` may
+        be one map or a contiguous run of maps (one launch); ``out``: a contiguous tensor of x's size to write into."""
         assert w == self.window
         if w == 0 and pre is None:
+            if out is not None:
+                out.copy_(x)
+                return out
             return x
-        out = torch.empty_like(x)
+        if out is None:
+            out = torch.empty_like(x)
         hip.affine_blend(x.contiguous(), pre, out, self.ss, float(w_pre), float(w_post), x.numel())
         return out
 
-    def blend(self, x, pre, i):
+    def blend(self, x, pre, i, out=None):
         """Cross-fade of the current window's slot 2 + i (aligned) onto ``pre``, the previous window's aligned slot 24 + i,
         with the weights of utils/util.py:67-73: 0, 1/7, ..., 6/7, 1 on the new window's side."""
         n = INTERP_LEN
         w_post = 0.0 if i == 0 else (1.0 if i == n - 1 else i * (1.0 / (n - 1)))
-        return self.apply(x, self.window, pre, 1.0 - w_post, w_post)
+        return self.apply(x, self.window, pre, 1.0 - w_post, w_post, out=out)
