@@ -871,3 +871,31 @@ def test_histogram_equalisation_and_temporal_refinement_on_device_match_the_orac
     prev = rs.rand(h, w).astype(np.float32) * 20
     want = np.stack(O.temporal_refine(list(scaled), list(flows), prev_depth=prev))
     assert np.array_equal(MP.temporal_refine(scaled, flows, prev_depth=prev), want)
+
+
+def test_video_path_ends_its_worker_threads_when_a_window_fails(vits):
+    """The whole-video path stages frames and copies results on worker threads.  A window that raises must not leave them
+    behind (waiting on a queue for ever), and the model must work afterwards."""
+    import threading
+    import time
+    from video_depth_anything.pipeline import run_video
+    model, _ = vits
+    frames = synth_frames(77, 28, 42, 321)
+    want, _ = model.infer_video_depth(frames, 24, input_size=28, device="cuda", batch_size=32)
+    before = threading.active_count()
+    calls = {"n": 0}
+
+    def failing_forward(x):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise RuntimeError("window 2 failed")
+        return model.forward(x)
+
+    with pytest.raises(RuntimeError, match="window 2 failed"):
+        run_video(model, frames, 24, input_size=28, device="cuda", batch_size=32, forward_fn=failing_forward)
+    deadline = time.time() + 5.0
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() == before
+    got, _ = model.infer_video_depth(frames, 24, input_size=28, device="cuda", batch_size=32)
+    assert np.array_equal(got, want)
