@@ -150,4 +150,13 @@ template <> __device__ __forceinline__ f16x4 read_tr<f16>(const char* p) {      
     return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(p)));
 }
 
+// Workgroup -> work item for grids whose neighbouring items read the same data (image rows, patches).  Consecutive workgroup
+// ids go to different XCDs (id mod 8), each with an L2 of its own, so neighbours dealt in id order fetch their shared
+// lines once per XCD.  This permutation of [0, n) hands XCD x a contiguous run of items, in the order it receives its
+// workgroups (bijective for any n).
+__device__ __forceinline__ int xcd_contiguous(int id, int n) {
+    const int q = n >> 3, r = n & 7, xcd = id & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
+
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }

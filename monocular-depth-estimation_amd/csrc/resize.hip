@@ -38,11 +38,12 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const T* __restrict_
                                                             int in_w, int out_h, int out_w, int C) {
     typedef typename Vec<T>::v8 v8;
     const unsigned cv = C / 8;
-    const int f = blockIdx.x / out_h, oy = blockIdx.x - f * out_h;
+    const int item = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);     // neighbouring rows share their source rows
+    const int f = item / out_h, oy = item - f * out_h;
     const Lerp ly = lerp_of(oy, in_h, out_h);
     const T* row0 = x + ((size_t)f * in_h + ly.i0) * in_w * C;
     const T* row1 = x + ((size_t)f * in_h + ly.i1) * in_w * C;
-    T* orow = out + (size_t)blockIdx.x * out_w * C;
+    T* orow = out + (size_t)item * out_w * C;
     const unsigned n = out_w * cv;
     for (unsigned i = threadIdx.x; i < n; i += 256) {
         const unsigned ox = i / cv, c = (i - ox * cv) * 8;
@@ -66,12 +67,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void bilinear_nhwc_pieces_kernel(const float* __restrict__ x, T* __restrict__ out, int in_h, int in_w,
                                                                    int out_h, int out_w, int C, float scale, int form, int* sat_flag) {
     const unsigned cv = C / 4;
-    const int f = blockIdx.x / out_h, oy = blockIdx.x - f * out_h;
+    const int item = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);     // neighbouring rows share their source rows
+    const int f = item / out_h, oy = item - f * out_h;
     const Lerp ly = lerp_of(oy, in_h, out_h);
     const float* row0 = x + ((size_t)f * in_h + ly.i0) * in_w * C;
     const float* row1 = x + ((size_t)f * in_h + ly.i1) * in_w * C;
     const int width = pieces_width(form, C);
-    T* orow = out + (size_t)blockIdx.x * out_w * width;
+    T* orow = out + (size_t)item * out_w * width;
     const unsigned n = out_w * cv;
     for (unsigned i = threadIdx.x; i < n; i += 256) {
         const unsigned ox = i / cv, c = (i - ox * cv) * 4;
@@ -93,11 +95,12 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_pieces_kernel(const float* 
 
 __global__ __launch_bounds__(256) void bilinear_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int in_h,
                                                            int in_w, int out_h, int out_w, int relu) {
-    const int f = blockIdx.x / out_h, oy = blockIdx.x - f * out_h;
+    const int item = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);     // neighbouring rows share their source rows
+    const int f = item / out_h, oy = item - f * out_h;
     const Lerp ly = lerp_of(oy, in_h, out_h);
     const float* row0 = x + ((size_t)f * in_h + ly.i0) * in_w;
     const float* row1 = x + ((size_t)f * in_h + ly.i1) * in_w;
-    float* orow = out + (size_t)blockIdx.x * out_w;
+    float* orow = out + (size_t)item * out_w;
     for (int ox = threadIdx.x; ox < out_w; ox += 256) {
         const Lerp lx = lerp_of(ox, in_w, out_w);
         float v = blend_px(ly, lx, row0[lx.i0], row0[lx.i1], row1[lx.i0], row1[lx.i1]);
